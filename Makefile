@@ -1,0 +1,20 @@
+# gpusort-mi355x — build the C-ABI library (gfx950 only) and the CPU oracle.
+HIPCC ?= hipcc
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC
+LIB := gpusorting_amd/lib/libgpusort.so
+SRC := gpusorting_amd/csrc/gpusort_capi.hip
+HDR := gpusorting_amd/csrc/onesweep_kernels.hpp include/gpusort.h
+
+all: $(LIB) oracle tools
+$(LIB): $(SRC) $(HDR)
+	@mkdir -p gpusorting_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
+oracle:
+	$(MAKE) -C oracle
+tools: build/gpusorting_main
+build/gpusorting_main: tools/gpusorting_main.cpp include/gpusort/OneSweepDispatcher.hpp $(LIB)
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Iinclude tools/gpusorting_main.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
+clean:
+	rm -rf build $(LIB); $(MAKE) -C oracle clean
+.PHONY: all oracle tools clean

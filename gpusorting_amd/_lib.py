@@ -1,0 +1,77 @@
+"""ctypes binding of libgpusort.so (the C-ABI of include/gpusort.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``make`` into ``gpusorting_amd/lib/libgpusort.so``.  There is NO fallback: if
+the library is missing, importing the binding raises — the product path never
+routes through the CPU oracle or any eager PyTorch op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpusort.so")
+
+GS_OK, GS_ERR_ARG, GS_ERR_SIZE, GS_ERR_HIP, GS_ERR_TIMEOUT, GS_ERR_MODE, GS_ERR_NO_DEVICE = range(7)
+GS_MAX_KEYS = (1 << 30) - 1
+GS_PROFILE_SLOTS = 8
+
+# every symbol include/gpusort.h declares: (name, restype, argtypes)
+_u32, _vp, _int = C.c_uint32, C.c_void_p, C.c_int
+_PROTOS = [
+    ("gs_version", C.c_char_p, []),
+    ("gs_status_string", C.c_char_p, [_int]),
+    ("gs_last_hip_error", _int, []),
+    ("gs_onesweep_create", _int, [C.POINTER(_vp), _u32, _int, _u32]),
+    ("gs_onesweep_destroy", _int, [_vp]),
+    ("gs_onesweep_temp_bytes", C.c_size_t, [_u32]),
+    ("gs_onesweep_partition_size", _u32, [_int, _u32]),
+    ("gs_onesweep_sort_keys", _int, [_vp, _vp, _vp, _u32, _int, _int, _vp]),
+    ("gs_onesweep_sort_pairs", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _int, _int, _vp]),
+    ("gs_onesweep_check", _int, [_vp, _vp]),
+    ("gs_onesweep_set_shape", _int, [_vp, _u32, _u32]),
+    ("gs_onesweep_get_partition_size", _u32, [_vp]),
+    ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
+    ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
+    ("gs_onesweep_set_profiling", _int, [_vp, _int]),
+    ("gs_onesweep_get_profile", _int, [_vp, C.POINTER(C.c_float)]),
+    ("gs_init_random", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    ("gs_validate", _int, [_vp, _vp, _u32, _u32, _int, _int, C.POINTER(_u32), _vp]),
+    ("gs_msd_splitters", _int, [C.POINTER(C.c_uint64), _u32, C.POINTER(_u32)]),
+]
+EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
+
+_lib = None
+
+
+class GpuSortError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = load().gs_status_string(status).decode()
+        if status == GS_ERR_HIP:
+            msg += f" (hipError {load().gs_last_hip_error()})"
+        super().__init__(f"{where}: {msg} [gs_status {status}]")
+
+
+def load() -> C.CDLL:
+    """Load libgpusort.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in _PROTOS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, where: str) -> None:
+    if status != GS_OK:
+        raise GpuSortError(status, where)

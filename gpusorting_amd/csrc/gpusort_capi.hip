@@ -1,0 +1,421 @@
+// gpusort_capi.hip — host side of libgpusort.so: the C-ABI of include/gpusort.h
+// over the gfx950 kernels of onesweep_kernels.hpp.
+//
+// Replaces the dispatch half of the reference's OneSweepDispatcher
+// (GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:301-391): state clear, the
+// 1 + 1 + 4 launch sequence, validation read-back.  Differences by design:
+//   - one hipMemsetAsync over ONE contiguous slab instead of 6 cudaMemset
+//     (:301-309) and no host sync inside the sort (:318);
+//   - descriptor rows = tiles + 1, so the last tile's publish to row tile+1
+//     stays in bounds (the reference overruns by 256 words when size==maxSize);
+//   - everything is enqueued on the caller's stream.
+#include "../../include/gpusort.h"
+#include "onesweep_kernels.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+#define GS_HIP(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) {                        \
+            g_last_hip_error = (int)e_;                \
+            return GS_ERR_HIP;                         \
+        }                                              \
+    } while (0)
+
+// ---- tile-shape table -------------------------------------------------------
+// One launcher per (shape, value bytes, key type).  Shape 0 is the default; the
+// others exist for on-device tuning sweeps (u32 keys only).
+using BinLauncher = void (*)(hipStream_t, uint32_t tiles, const uint32_t*, uint32_t*, const void*, void*,
+                             uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
+                             uint32_t reverse);
+
+template <int THREADS, int KPT, int VB, int KT>
+void launch_bin(hipStream_t s, uint32_t tiles, const uint32_t* kin, uint32_t* kout, const void* vin, void* vout,
+                uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
+                uint32_t reverse) {
+    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT>), dim3(tiles), dim3(THREADS), 0, s, kin,
+                       kout, vin, vout, desc, counter, status, n, shift, reverse);
+}
+
+struct Shape {
+    int threads, kpt;
+    BinLauncher fn[3][3];  // [vb index 0/4/8][key type]; nullptr = not compiled
+};
+
+#define GS_FULL(T, K)                                                                              \
+    {                                                                                              \
+        T, K, {                                                                                    \
+            {launch_bin<T, K, 0, 0>, launch_bin<T, K, 0, 1>, launch_bin<T, K, 0, 2>},              \
+                {launch_bin<T, K, 4, 0>, launch_bin<T, K, 4, 1>, launch_bin<T, K, 4, 2>},          \
+                {launch_bin<T, K, 8, 0>, launch_bin<T, K, 8, 1>, launch_bin<T, K, 8, 2>},          \
+        }                                                                                          \
+    }
+#define GS_U32ONLY(T, K)                                                                           \
+    {                                                                                              \
+        T, K, {                                                                                    \
+            {launch_bin<T, K, 0, 0>, nullptr, nullptr}, {launch_bin<T, K, 4, 0>, nullptr, nullptr}, \
+                {launch_bin<T, K, 8, 0>, nullptr, nullptr},                                        \
+        }                                                                                          \
+    }
+
+const Shape g_shapes[] = {
+    GS_FULL(512, 16),  // default
+#ifndef GS_NO_TUNING_SHAPES
+    GS_U32ONLY(256, 16), GS_U32ONLY(512, 8),   GS_U32ONLY(1024, 8),
+    GS_U32ONLY(256, 32), GS_U32ONLY(512, 32),  GS_U32ONLY(1024, 16),
+#endif
+};
+constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
+
+inline int vb_index(uint32_t vb) { return vb == 0 ? 0 : vb == 4 ? 1 : 2; }
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- state slab layout (uint32 words) ----------------------------------------
+//  [0..3]   tile ticket counters, one per pass      (reference m_index)
+//  [4]      device status word
+//  [16..1039] global histogram, 4 x 256            (reference m_globalHistogram)
+//  [1040..] descriptors: pass p at 1040 + p*(tiles+1)*256, (tiles+1) rows of 256
+constexpr uint32_t SLAB_COUNTERS = 0, SLAB_STATUS = 4, SLAB_GHIST = 16, SLAB_DESC = 16 + 1024;
+
+constexpr uint32_t MIN_TILE = 2048;  // smallest tile of any compiled shape (sizing of the slab)
+
+}  // namespace
+
+struct gs_onesweep {
+    uint32_t max_keys;
+    gs_mode mode;
+    uint32_t value_bytes;
+    int shape;
+    uint32_t* slab;
+    size_t slab_words;
+    int profiling;
+    hipEvent_t ev[GS_PROFILE_SLOTS + 1];
+    bool ev_valid;
+    bool profile_pending;
+    uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
+};
+
+namespace {
+
+size_t slab_words_for(uint32_t max_keys) {
+    const size_t max_tiles = div_up(max_keys, MIN_TILE);
+    return SLAB_DESC + 4 * (max_tiles + 1) * (size_t)gs::RADIX;
+}
+
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+template <int KT>
+void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* ghist, uint32_t n) {
+    hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, ghist, n);
+}
+const HistLauncher g_hist[3] = {launch_hist<0>, launch_hist<1>, launch_hist<2>};
+
+uint32_t hist_blocks(uint32_t n) {
+    // 16 keys per thread-iteration block sweep; cap at 8 blocks per CU, grid-stride beyond
+    const uint32_t want = div_up(n, gs::GHIST_THREADS * 4 * 4);
+    const uint32_t cap = 256 * 8;
+    return want < 1 ? 1 : (want > cap ? cap : want);
+}
+
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+// Clears the scan state and runs GlobalHistogram + Scan.  Returns tiles.
+gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t* tiles_out,
+                   uint32_t* desc_stride_out) {
+    const Shape& sh = g_shapes[h->shape];
+    const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
+    const uint32_t tiles = div_up(n, tile);
+    const uint32_t desc_stride = (tiles + 1) * gs::RADIX;
+    const size_t used_words = SLAB_DESC + 4 * (size_t)desc_stride;
+    if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
+    GS_HIP(hipMemsetAsync(h->slab, 0, used_words * sizeof(uint32_t), s));
+    if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
+    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_GHIST, n);
+    if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
+    hipLaunchKernelGGL(gs::scan_kernel, dim3(4), dim3(256), 0, s, h->slab + SLAB_GHIST, h->slab + SLAB_DESC, desc_stride);
+    if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
+    *tiles_out = tiles;
+    *desc_stride_out = desc_stride;
+    return GS_OK;
+}
+
+gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n, gs_key_type kt, gs_order order) {
+    if (!h || !a || !b || misaligned(a) || misaligned(b)) return GS_ERR_ARG;
+    if ((int)kt < 0 || (int)kt > 2 || (int)order < 0 || (int)order > 1) return GS_ERR_ARG;
+    if (n == 0 || n > h->max_keys || n > GS_MAX_KEYS) return GS_ERR_SIZE;
+    return GS_OK;
+}
+
+gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
+                    gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
+    const Shape& sh = g_shapes[h->shape];
+    BinLauncher fn = sh.fn[vb_index(vb)][kt];
+    if (!fn) return GS_ERR_ARG;
+    uint32_t tiles = 0, desc_stride = 0;
+    gs_status st = prologue(h, d_keys, n, kt, s, &tiles, &desc_stride);
+    if (st != GS_OK) return st;
+    uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
+    void* v[2] = {d_vals, d_alt_vals};
+    for (uint32_t p = 0; p < 4; ++p) {
+        const uint32_t reverse = (order == GS_ORDER_DESCENDING && p == 3) ? 1u : 0u;
+        fn(s, tiles, k[p & 1], k[(p + 1) & 1], v[p & 1], v[(p + 1) & 1], h->slab + SLAB_DESC + (size_t)p * desc_stride,
+           h->slab + SLAB_COUNTERS + p, h->slab + SLAB_STATUS, n, p * 8, reverse);
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
+    }
+    GS_HIP(hipGetLastError());
+    h->profile_pending = h->profiling != 0;
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gs_version(void) { return "gpusort-mi355x 0.1 (gfx950 OneSweep)"; }
+
+const char* gs_status_string(gs_status s) {
+    switch (s) {
+        case GS_OK: return "ok";
+        case GS_ERR_ARG: return "bad argument";
+        case GS_ERR_SIZE: return "bad size";
+        case GS_ERR_HIP: return "HIP runtime error";
+        case GS_ERR_TIMEOUT: return "look-back timeout on device";
+        case GS_ERR_MODE: return "mode / value width mismatch";
+        case GS_ERR_NO_DEVICE: return "no GPU device";
+    }
+    return "unknown";
+}
+
+int gs_last_hip_error(void) { return g_last_hip_error; }
+
+size_t gs_onesweep_temp_bytes(uint32_t max_keys) { return slab_words_for(max_keys) * sizeof(uint32_t); }
+
+uint32_t gs_onesweep_partition_size(gs_mode, uint32_t) {
+    return (uint32_t)g_shapes[0].threads * g_shapes[0].kpt;
+}
+
+gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes) {
+    if (!out) return GS_ERR_ARG;
+    *out = nullptr;
+    if (max_keys == 0 || max_keys > GS_MAX_KEYS) return GS_ERR_SIZE;
+    if (mode == GS_MODE_KEYS_ONLY) {
+        if (value_bytes != 0) return GS_ERR_MODE;
+    } else if (mode == GS_MODE_PAIRS) {
+        if (value_bytes != 4 && value_bytes != 8) return GS_ERR_MODE;
+    } else {
+        return GS_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return GS_ERR_NO_DEVICE;
+    gs_onesweep* h = new (std::nothrow) gs_onesweep();
+    if (!h) return GS_ERR_ARG;
+    h->max_keys = max_keys;
+    h->mode = mode;
+    h->value_bytes = value_bytes;
+    h->shape = 0;
+    h->profiling = 0;
+    h->ev_valid = false;
+    h->profile_pending = false;
+    h->slab = nullptr;
+    h->pinned = nullptr;
+    h->slab_words = slab_words_for(max_keys);
+    if (const char* env = getenv("GPUSORT_SHAPE")) {  // e.g. "512x16"
+        int t = 0, k = 0;
+        if (sscanf(env, "%dx%d", &t, &k) == 2)
+            for (int i = 0; i < g_num_shapes; ++i)
+                if (g_shapes[i].threads == t && g_shapes[i].kpt == k) h->shape = i;
+    }
+    hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (1024 + 8) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        if (h->slab) (void)hipFree(h->slab);
+        delete h;
+        return GS_ERR_HIP;
+    }
+    *out = h;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_destroy(gs_onesweep* h) {
+    if (!h) return GS_ERR_ARG;
+    if (h->ev_valid)
+        for (auto& e : h->ev) (void)hipEventDestroy(e);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->slab) (void)hipFree(h->slab);
+    delete h;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread) {
+    if (!h) return GS_ERR_ARG;
+    for (int i = 0; i < g_num_shapes; ++i)
+        if ((uint32_t)g_shapes[i].threads == threads && (uint32_t)g_shapes[i].kpt == keys_per_thread) {
+            h->shape = i;
+            return GS_OK;
+        }
+    return GS_ERR_ARG;
+}
+
+uint32_t gs_onesweep_get_partition_size(gs_onesweep* h) {
+    return h ? (uint32_t)g_shapes[h->shape].threads * g_shapes[h->shape].kpt : 0;
+}
+
+gs_status gs_onesweep_sort_keys(gs_onesweep* h, void* d_keys, void* d_alt, uint32_t n, gs_key_type kt, gs_order order,
+                                void* stream) {
+    gs_status st = check_common(h, d_keys, d_alt, n, kt, order);
+    if (st != GS_OK) return st;
+    return sort_impl(h, d_keys, nullptr, d_alt, nullptr, n, kt, order, static_cast<hipStream_t>(stream), 0);
+}
+
+gs_status gs_onesweep_sort_pairs(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals,
+                                 uint32_t n, gs_key_type kt, gs_order order, void* stream) {
+    gs_status st = check_common(h, d_keys, d_alt_keys, n, kt, order);
+    if (st != GS_OK) return st;
+    if (h->mode != GS_MODE_PAIRS) return GS_ERR_MODE;
+    if (!d_vals || !d_alt_vals || misaligned(d_vals) || misaligned(d_alt_vals)) return GS_ERR_ARG;
+    return sort_impl(h, d_keys, d_vals, d_alt_keys, d_alt_vals, n, kt, order, static_cast<hipStream_t>(stream),
+                     h->value_bytes);
+}
+
+gs_status gs_onesweep_check(gs_onesweep* h, void* stream) {
+    if (!h) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_STATUS, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    return h->pinned[0] == gs::STATUS_OK ? GS_OK : GS_ERR_TIMEOUT;
+}
+
+gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, uint32_t* h_hist,
+                                       void* stream) {
+    if (!h || !d_keys || !h_hist || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n == 0 || n > h->max_keys) return GS_ERR_SIZE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t tiles, stride;
+    gs_status st = prologue(h, d_keys, n, kt, s, &tiles, &stride);
+    if (st != GS_OK) return st;
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_GHIST, 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    memcpy(h_hist, h->pinned, 1024 * sizeof(uint32_t));
+    return GS_OK;
+}
+
+gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_keys_out, const void* d_vals_in,
+                                 void* d_vals_out, uint32_t n, uint32_t pass, gs_key_type kt, int reverse_index,
+                                 void* stream) {
+    gs_status st = check_common(h, d_keys_in, d_keys_out, n, kt, GS_ORDER_ASCENDING);
+    if (st != GS_OK) return st;
+    if (pass > 3) return GS_ERR_ARG;
+    uint32_t vb = 0;
+    if (d_vals_in || d_vals_out) {
+        if (h->mode != GS_MODE_PAIRS) return GS_ERR_MODE;
+        if (!d_vals_in || !d_vals_out || misaligned(d_vals_in) || misaligned(d_vals_out)) return GS_ERR_ARG;
+        vb = h->value_bytes;
+    }
+    const Shape& sh = g_shapes[h->shape];
+    BinLauncher fn = sh.fn[vb_index(vb)][kt];
+    if (!fn) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t tiles, stride;
+    st = prologue(h, d_keys_in, n, kt, s, &tiles, &stride);
+    if (st != GS_OK) return st;
+    fn(s, tiles, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
+       h->slab + SLAB_DESC + (size_t)pass * stride, h->slab + SLAB_COUNTERS + pass, h->slab + SLAB_STATUS, n, pass * 8,
+       reverse_index ? 1u : 0u);
+    GS_HIP(hipGetLastError());
+    h->profile_pending = false;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_profiling(gs_onesweep* h, int enabled) {
+    if (!h) return GS_ERR_ARG;
+    if (enabled && !h->ev_valid) {
+        for (auto& e : h->ev) GS_HIP(hipEventCreate(&e));
+        h->ev_valid = true;
+    }
+    h->profiling = enabled ? 1 : 0;
+    h->profile_pending = false;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_get_profile(gs_onesweep* h, float ms[GS_PROFILE_SLOTS]) {
+    if (!h || !ms) return GS_ERR_ARG;
+    if (!h->profile_pending) return GS_ERR_ARG;
+    GS_HIP(hipEventSynchronize(h->ev[7]));
+    for (int i = 0; i < 7; ++i) GS_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms[7], h->ev[0], h->ev[7]));
+    return GS_OK;
+}
+
+gs_status gs_init_random(void* d_keys, void* d_vals, uint32_t value_bytes, uint32_t and_count, uint32_t seed, uint32_t n,
+                         void* stream) {
+    if (!d_keys || n == 0) return n == 0 ? GS_ERR_SIZE : GS_ERR_ARG;
+    if (and_count > 31) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* k = static_cast<uint32_t*>(d_keys);
+    if (!d_vals || value_bytes == 0)
+        hipLaunchKernelGGL(gs::init_random_kernel<0>, dim3(256), dim3(256), 0, s, k, nullptr, and_count, seed, n);
+    else if (value_bytes == 4)
+        hipLaunchKernelGGL(gs::init_random_kernel<4>, dim3(256), dim3(256), 0, s, k, d_vals, and_count, seed, n);
+    else if (value_bytes == 8)
+        hipLaunchKernelGGL(gs::init_random_kernel<8>, dim3(256), dim3(256), 0, s, k, d_vals, and_count, seed, n);
+    else
+        return GS_ERR_MODE;
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_bytes, uint32_t n, gs_key_type kt,
+                      gs_order order, uint32_t* h_err_count, void* stream) {
+    if (!d_keys || !h_err_count || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n == 0) return GS_ERR_SIZE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* d_err = nullptr;
+    GS_HIP(hipMalloc(&d_err, sizeof(uint32_t)));
+    gs_status ret = GS_OK;
+    do {
+        if (hipMemsetAsync(d_err, 0, sizeof(uint32_t), s) != hipSuccess) { ret = GS_ERR_HIP; break; }
+        const uint32_t blocks = div_up(n, 256 * 16) < 2048 ? div_up(n, 256 * 16) : 2048;
+        const uint32_t* k = static_cast<const uint32_t*>(d_keys);
+        const int desc = order == GS_ORDER_DESCENDING;
+        if (!d_vals || value_bytes == 0)
+            hipLaunchKernelGGL(gs::validate_kernel<0>, dim3(blocks), dim3(256), 0, s, k, nullptr, n, (int)kt, desc, d_err);
+        else if (value_bytes == 4)
+            hipLaunchKernelGGL(gs::validate_kernel<4>, dim3(blocks), dim3(256), 0, s, k, d_vals, n, (int)kt, desc, d_err);
+        else if (value_bytes == 8)
+            hipLaunchKernelGGL(gs::validate_kernel<8>, dim3(blocks), dim3(256), 0, s, k, d_vals, n, (int)kt, desc, d_err);
+        else { ret = GS_ERR_MODE; break; }
+        if (hipMemcpyAsync(h_err_count, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            ret = GS_ERR_HIP;
+    } while (0);
+    (void)hipFree(d_err);
+    return ret;
+}
+
+gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t* first_bin) {
+    if (!hist256 || !first_bin || world == 0 || world > 256) return GS_ERR_ARG;
+    uint64_t total = 0;
+    for (int b = 0; b < 256; ++b) total += hist256[b];
+    // Rank r starts at the first top-byte bin whose exclusive prefix reaches
+    // ceil(r * total / world): equal-count buckets at bin granularity.
+    first_bin[0] = 0;
+    uint64_t excl = 0;
+    uint32_t b = 0;
+    for (uint32_t r = 1; r < world; ++r) {
+        const uint64_t target = (total * r + world - 1) / world;
+        while (b < 256 && excl < target) excl += hist256[b++];
+        first_bin[r] = b;
+    }
+    first_bin[world] = 256;
+    return GS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference's OneSweep dispatch surface, over the C-ABI.
+
+Reference interfaces mirrored (paths relative to the reference root):
+  * ``GPUSortingConfig`` / MODE / ORDER / KEY_TYPE / ENTROPY_PRESET enums —
+    GPUSortingD3D12/GPUSorting.h:40-86
+  * ``OneSweep`` — D3D12 ``OneSweep(device, deviceInfo, ORDER, KEY_TYPE[, PAYLOAD_TYPE])``
+    (GPUSortingD3D12/OneSweep.h:16-27) with Unity's caller-owned-buffer
+    ``Sort(...)`` (GPUSortingUnity/Runtime/OneSweep.cs:297-427)
+  * ``OneSweepDispatcher`` — the CUDA tree's class, same method names, arguments
+    and print format (GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:17-392)
+
+PyTorch is used only for device memory and the current HIP stream; every
+computation goes through libgpusort.so (hand-written gfx950 kernels).  There is
+no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+MODE_KEYS_ONLY, MODE_PAIRS = 0, 1
+ORDER_ASCENDING, ORDER_DESCENDING = 0, 1
+KEY_UINT32, KEY_INT32, KEY_FLOAT32 = 0, 1, 2
+PAYLOAD_UINT32, PAYLOAD_INT32, PAYLOAD_FLOAT32 = 0, 1, 2
+ENTROPY_PRESET_1, ENTROPY_PRESET_2, ENTROPY_PRESET_3, ENTROPY_PRESET_4, ENTROPY_PRESET_5 = range(5)
+_ENT_LOOKUP = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201
+
+_KEY_DTYPES = {torch.uint32: KEY_UINT32, torch.int32: KEY_INT32, torch.float32: KEY_FLOAT32}
+
+
+@dataclass
+class GPUSortingConfig:
+    """GPUSortingD3D12/GPUSorting.h:70-76."""
+    sortingMode: int = MODE_KEYS_ONLY
+    sortingOrder: int = ORDER_ASCENDING
+    sortingKeyType: int = KEY_UINT32
+    sortingPayloadType: int = PAYLOAD_UINT32
+
+
+def _stream_ptr(stream=None) -> int:
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous tensor on the GPU")
+
+
+def init_random(keys: torch.Tensor, seed: int, entropy_preset: int = ENTROPY_PRESET_1,
+                values: torch.Tensor | None = None, n: int | None = None) -> None:
+    """InitRandom<<<256,256>>> (GPUSortingCUDA/UtilityKernels.cuh:53-117): fills keys (and values = key)."""
+    _require_cuda(keys, "keys")
+    n = keys.numel() if n is None else n
+    vb = 0 if values is None else values.element_size()
+    check(_lib.load().gs_init_random(keys.data_ptr(), None if values is None else values.data_ptr(), vb,
+                                     int(entropy_preset), seed & 0xFFFFFFFF, n, _stream_ptr()), "gs_init_random")
+
+
+def validate(keys: torch.Tensor, values: torch.Tensor | None = None, n: int | None = None,
+             key_type: int = KEY_UINT32, order: int = ORDER_ASCENDING) -> int:
+    """Validate (GPUSortingCUDA/UtilityKernels.cuh:402-479): number of adjacent inversions (0 == sorted)."""
+    _require_cuda(keys, "keys")
+    n = keys.numel() if n is None else n
+    err = C.c_uint32(0xFFFFFFFF)
+    vb = 0 if values is None else values.element_size()
+    check(_lib.load().gs_validate(keys.data_ptr(), None if values is None else values.data_ptr(), vb, n, key_type,
+                                  order, C.byref(err), _stream_ptr()), "gs_validate")
+    return int(err.value)
+
+
+class OneSweep:
+    """One sorter object == one ``gs_onesweep`` handle (scan state) + lazily sized alt buffers."""
+
+    def __init__(self, max_keys: int, order: int = ORDER_ASCENDING, key_type: int = KEY_UINT32,
+                 mode: int = MODE_KEYS_ONLY, value_bytes: int = 0, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("gpusorting_amd needs a GPU: the product path has no CPU fallback")
+        self._lib = _lib.load()
+        if device is not None:
+            torch.cuda.set_device(device)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.max_keys = int(max_keys)
+        self.order, self.key_type, self.mode = order, key_type, mode
+        self.value_bytes = value_bytes if mode == MODE_PAIRS else 0
+        if mode == MODE_PAIRS and self.value_bytes == 0:
+            self.value_bytes = 4
+        h = C.c_void_p()
+        check(self._lib.gs_onesweep_create(C.byref(h), self.max_keys, mode, self.value_bytes), "gs_onesweep_create")
+        self._h = h
+        self._alt_keys = None
+        self._alt_vals = None
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.gs_onesweep_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_config(cls, max_keys: int, cfg: GPUSortingConfig, value_bytes: int = 4) -> "OneSweep":
+        return cls(max_keys, cfg.sortingOrder, cfg.sortingKeyType, cfg.sortingMode,
+                   value_bytes if cfg.sortingMode == MODE_PAIRS else 0)
+
+    # -- helpers ------------------------------------------------------------
+    @property
+    def partition_size(self) -> int:
+        return int(self._lib.gs_onesweep_get_partition_size(self._h))
+
+    def set_shape(self, threads: int, keys_per_thread: int) -> None:
+        check(self._lib.gs_onesweep_set_shape(self._h, threads, keys_per_thread), "gs_onesweep_set_shape")
+
+    def _alts(self, n: int, values: torch.Tensor | None):
+        if self._alt_keys is None or self._alt_keys.numel() < n:
+            self._alt_keys = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        if values is not None and (self._alt_vals is None or self._alt_vals.numel() < n
+                                   or self._alt_vals.element_size() != values.element_size()):
+            dt = torch.int32 if values.element_size() == 4 else torch.int64
+            self._alt_vals = torch.empty(max(n, 1), dtype=dt, device=self.device)
+        return self._alt_keys, (self._alt_vals if values is not None else None)
+
+    # -- the hot path ---------------------------------------------------------
+    def sort(self, keys: torch.Tensor, values: torch.Tensor | None = None, n: int | None = None,
+             alt_keys: torch.Tensor | None = None, alt_values: torch.Tensor | None = None, stream=None) -> None:
+        """Sort ``keys[:n]`` (and ``values[:n]``) in place on the current stream (asynchronous).
+
+        Unity ``OneSweep.Sort`` (OneSweep.cs:297-427): the caller may pass its own
+        temp buffers (``alt_*``); otherwise the object keeps a pair.
+        """
+        _require_cuda(keys, "keys")
+        n = keys.numel() if n is None else int(n)
+        if keys.element_size() != 4:
+            raise ValueError("keys must be a 32-bit type")
+        if (values is not None) != (self.mode == MODE_PAIRS):
+            raise ValueError("values must be given exactly when the sorter was built with MODE_PAIRS")
+        if alt_keys is None:
+            alt_keys, own_alt_vals = self._alts(n, values)
+            if alt_values is None:
+                alt_values = own_alt_vals
+        s = _stream_ptr(stream)
+        if values is None:
+            st = self._lib.gs_onesweep_sort_keys(self._h, keys.data_ptr(), alt_keys.data_ptr(), n, self.key_type,
+                                                 self.order, s)
+        else:
+            _require_cuda(values, "values")
+            if values.element_size() != self.value_bytes:
+                raise ValueError(f"values must be {self.value_bytes}-byte elements")
+            st = self._lib.gs_onesweep_sort_pairs(self._h, keys.data_ptr(), values.data_ptr(), alt_keys.data_ptr(),
+                                                  alt_values.data_ptr(), n, self.key_type, self.order, s)
+        check(st, "gs_onesweep_sort")
+
+    def check(self, stream=None) -> None:
+        """Synchronise and raise if the device reported a look-back timeout."""
+        check(self._lib.gs_onesweep_check(self._h, _stream_ptr(stream)), "gs_onesweep_check")
+
+    # -- structural entry points ------------------------------------------------
+    def global_histogram(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
+        n = keys.numel() if n is None else int(n)
+        out = (C.c_uint32 * 1024)()
+        check(self._lib.gs_onesweep_global_histogram(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
+              "gs_onesweep_global_histogram")
+        return np.frombuffer(out, dtype=np.uint32).reshape(4, 256).copy()
+
+    def digit_pass(self, keys_in: torch.Tensor, keys_out: torch.Tensor, pass_index: int, n: int | None = None,
+                   values_in: torch.Tensor | None = None, values_out: torch.Tensor | None = None,
+                   reverse_index: bool = False) -> None:
+        n = keys_in.numel() if n is None else int(n)
+        check(self._lib.gs_onesweep_digit_pass(
+            self._h, keys_in.data_ptr(), keys_out.data_ptr(),
+            None if values_in is None else values_in.data_ptr(),
+            None if values_out is None else values_out.data_ptr(), n, pass_index, self.key_type,
+            1 if reverse_index else 0, _stream_ptr()), "gs_onesweep_digit_pass")
+
+    # -- profiling ------------------------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        check(self._lib.gs_onesweep_set_profiling(self._h, 1 if enabled else 0), "gs_onesweep_set_profiling")
+
+    def get_profile(self) -> dict:
+        ms = (C.c_float * _lib.GS_PROFILE_SLOTS)()
+        check(self._lib.gs_onesweep_get_profile(self._h, ms), "gs_onesweep_get_profile")
+        names = ("clear", "global_histogram", "scan", "pass0", "pass1", "pass2", "pass3", "total")
+        return {k: float(v) for k, v in zip(names, ms)}
+
+
+class OneSweepDispatcher:
+    """The CUDA tree's benchmark/test class, method for method.
+
+    GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:17-392.  Like the reference it
+    owns its buffers (``m_sort``, ``m_alt``, payloads) and generates inputs on
+    the device; prints the same lines.  ``quick`` shortens ``TestAll*`` for CI
+    (the reference has no such switch).
+    """
+
+    def __init__(self, keysOnly: bool, maxSize: int, value_bytes: int = 4, out=print):
+        self.k_keysOnly = bool(keysOnly)
+        self.k_maxSize = int(maxSize)
+        self._out = out
+        self._sorter = OneSweep(self.k_maxSize, mode=MODE_KEYS_ONLY if keysOnly else MODE_PAIRS,
+                                value_bytes=0 if keysOnly else value_bytes)
+        self.k_partitionSize = self._sorter.partition_size
+        dev = self._sorter.device
+        self.m_sort = torch.empty(self.k_maxSize, dtype=torch.int32, device=dev)
+        self.m_alt = torch.empty(self.k_maxSize, dtype=torch.int32, device=dev)
+        self.m_sortPayload = self.m_altPayload = None
+        if not keysOnly:
+            dt = torch.int32 if value_bytes == 4 else torch.int64
+            self.m_sortPayload = torch.empty(self.k_maxSize, dtype=dt, device=dev)
+            self.m_altPayload = torch.empty(self.k_maxSize, dtype=dt, device=dev)
+
+    # private members of the reference, kept with their names
+    def DispatchKernelsKeysOnly(self, size: int) -> None:
+        self._sorter.sort(self.m_sort, n=size, alt_keys=self.m_alt)
+
+    def DispatchKernelsPairs(self, size: int) -> None:
+        self._sorter.sort(self.m_sort, self.m_sortPayload, n=size, alt_keys=self.m_alt, alt_values=self.m_altPayload)
+
+    def DispatchValidateKeys(self, size: int) -> bool:
+        return validate(self.m_sort, n=size) == 0
+
+    def DispatchValidatePairs(self, size: int) -> bool:
+        return validate(self.m_sort, self.m_sortPayload, n=size) == 0
+
+    def _test_all(self, pairs: bool, quick: bool) -> bool:
+        if self.k_maxSize < (1 << 28) and not quick:
+            self._out(f"This test requires a minimum initialized size of {1 << 28}. "
+                      f"Reinitialize the object to at least {1 << 28}.")
+            return False
+        if pairs and self.k_keysOnly:
+            self._out("Error, object was intialized for keys only")
+            return False
+        self._out(f"Beginning GPUSorting OneSweep {'pairs' if pairs else 'keys'} validation test: ")
+        P = self.k_partitionSize
+        sizes = list(range(P, 2 * P + 1, 97 if quick else 1))
+        if quick and sizes[-1] != 2 * P:
+            sizes.append(2 * P)
+        big = [e for e in (26, 27, 28) if (1 << e) <= self.k_maxSize]
+        passed, dots = 0, []
+        for i in sizes:
+            init_random(self.m_sort, i, ENTROPY_PRESET_1, self.m_sortPayload if pairs else None, n=i)
+            (self.DispatchKernelsPairs if pairs else self.DispatchKernelsKeysOnly)(i)
+            if (self.DispatchValidatePairs if pairs else self.DispatchValidateKeys)(i):
+                passed += 1
+            else:
+                self._out(f"\n Test failed at size {i} ")
+            if not (i & 255):
+                dots.append(".")
+        self._out("".join(dots))
+        for e in big:
+            init_random(self.m_sort, e, ENTROPY_PRESET_1, self.m_sortPayload if pairs else None, n=1 << e)
+            (self.DispatchKernelsPairs if pairs else self.DispatchKernelsKeysOnly)(1 << e)
+            if (self.DispatchValidatePairs if pairs else self.DispatchValidateKeys)(1 << e):
+                passed += 1
+            else:
+                self._out(f"\n Test failed at size {1 << e} ")
+        self._sorter.check()
+        expected = len(sizes) + len(big)
+        if passed == expected:
+            self._out(f"{passed}/{passed} All tests passed.\n")
+        else:
+            self._out(f"{passed}/{expected} Test failed.\n")
+        return passed == expected
+
+    def TestAllKeysOnly(self, quick: bool = False) -> bool:
+        return self._test_all(False, quick)
+
+    def TestAllPairs(self, quick: bool = False) -> bool:
+        return self._test_all(True, quick)
+
+    def _batch_timing(self, pairs: bool, size: int, batchCount: int, seed: int, entropyPreset: int) -> float:
+        if pairs and self.k_keysOnly:
+            self._out("Error, object was intialized for keys only")
+            return 0.0
+        if size > self.k_maxSize:
+            self._out("Error, requested test size exceeds max initialized size. ")
+            return 0.0
+        self._out(f"Beginning GPUSorting OneSweep {'pairs' if pairs else 'keys'} batch timing test at:")
+        self._out(f"Size: {size}")
+        self._out(f"Entropy: {_ENT_LOOKUP[entropyPreset]:f} bits")
+        self._out(f"Test size: {batchCount}")
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        total = 0.0
+        for i in range(batchCount + 1):
+            # the reference's BatchTimingPairs leaves the payload uninitialised
+            # (OneSweepDispatcher.cuh:269-273); we initialise value = key.
+            init_random(self.m_sort, i + seed, entropyPreset, self.m_sortPayload if pairs else None, n=size)
+            torch.cuda.synchronize()
+            start.record()
+            (self.DispatchKernelsPairs if pairs else self.DispatchKernelsKeysOnly)(size)
+            stop.record()
+            stop.synchronize()
+            if i:
+                total += start.elapsed_time(stop)
+        total /= 1000.0
+        self._out(f"Total time elapsed: {total:f}")
+        rate = size / total * batchCount if total > 0 else 0.0
+        self._out(f"Estimated speed at {size} 32-bit elements: {rate:E} keys/sec\n")
+        return rate
+
+    def BatchTimingKeysOnly(self, size: int, batchCount: int, seed: int, entropyPreset: int) -> float:
+        return self._batch_timing(False, size, batchCount, seed, entropyPreset)
+
+    def BatchTimingPairs(self, size: int, batchCount: int, seed: int, entropyPreset: int) -> float:
+        return self._batch_timing(True, size, batchCount, seed, entropyPreset)

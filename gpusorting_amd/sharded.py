@@ -1,0 +1,126 @@
+"""Multi-GPU sharded sort: one MSD split + RCCL all-to-all-v + per-GPU OneSweep.
+
+No reference counterpart (the reference is single-GPU); this is
+BASELINE.json configs[3].  One process per GPU, ``torch.distributed`` (backend
+"nccl" == RCCL over xGMI).  Steps on every rank, all on the rank's own data:
+
+  1. top-byte histogram of the local shard (the GlobalHistogram kernel's row 3)
+  2. ONE small all_gather of the 256-bin histograms -> every rank knows every
+     (source, bin) count, hence the global histogram, the splitters
+     (``gs_msd_splitters``: equal-count buckets at top-byte granularity) and all
+     send/receive counts without a second exchange
+  3. a stable DigitBinningPass on the top byte groups the shard by destination
+  4. ``all_to_all_single`` with split sizes (RCCL AllToAllv; point-to-point on
+     all xGMI links at once) moves every key to its owner
+  5. the local 4-pass OneSweep sorts the received bucket
+Result: rank r holds the r-th contiguous range of the globally sorted array
+(concatenation over ranks == the sorted whole).  Received data is ordered by
+(source rank, source position), so for pairs the whole pipeline is stable.
+
+The local engine is injected (``HipLocalEngine`` is the product; the CPU tests
+inject an oracle-backed engine and run the same control flow over gloo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def msd_splitters(hist256: np.ndarray, world: int) -> np.ndarray:
+    """first_bin[r] = first top-byte value rank r owns; host-side C-ABI call."""
+    h = np.ascontiguousarray(hist256, dtype=np.uint64)
+    fb = (C.c_uint32 * (world + 1))()
+    _lib.check(_lib.load().gs_msd_splitters(h.ctypes.data_as(C.POINTER(C.c_uint64)), world, fb), "gs_msd_splitters")
+    return np.frombuffer(fb, dtype=np.uint32).copy()
+
+
+class HipLocalEngine:
+    """Per-rank work on the GPU through libgpusort.so."""
+
+    def __init__(self, capacity: int, pairs: bool = False, value_bytes: int = 4, key_type: int = 0):
+        from .onesweep import MODE_KEYS_ONLY, MODE_PAIRS, OneSweep
+        self.sorter = OneSweep(capacity, key_type=key_type, mode=MODE_PAIRS if pairs else MODE_KEYS_ONLY,
+                               value_bytes=value_bytes if pairs else 0)
+        self.device = self.sorter.device
+
+    def empty_like_keys(self, n):
+        return torch.empty(n, dtype=torch.int32, device=self.device)
+
+    def top_byte_histogram(self, keys, n) -> np.ndarray:
+        return self.sorter.global_histogram(keys, n)[3].astype(np.int64)
+
+    def partition_by_top_byte(self, keys, out, n, values=None, values_out=None):
+        self.sorter.digit_pass(keys, out, 3, n=n, values_in=values, values_out=values_out)
+
+    def sort(self, keys, n, values=None):
+        self.sorter.sort(keys, values, n=n)
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+
+class ShardedOneSweep:
+    def __init__(self, shard_keys: int, engine=None, group=None, slack: float = 1.25, pairs: bool = False,
+                 value_bytes: int = 4):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.shard_keys = int(shard_keys)
+        self.capacity = min(int(shard_keys * slack) + 256, _lib.GS_MAX_KEYS)
+        self.pairs = pairs
+        self.engine = engine if engine is not None else HipLocalEngine(self.capacity, pairs, value_bytes)
+        dev = self.engine.device
+        self._part = self.engine.empty_like_keys(self.shard_keys)
+        self._recv = self.engine.empty_like_keys(self.capacity)
+        self._part_v = self._recv_v = None
+        if pairs:
+            dt = torch.int32 if value_bytes == 4 else torch.int64
+            self._part_v = torch.empty(self.shard_keys, dtype=dt, device=dev)
+            self._recv_v = torch.empty(self.capacity, dtype=dt, device=dev)
+        self._gather = torch.empty(self.world * 256, dtype=torch.int64, device=dev)
+        self.last_counts = None
+
+    def sort(self, keys: torch.Tensor, n: int | None = None, values: torch.Tensor | None = None):
+        """Sort the distributed array whose local shard is ``keys[:n]``.
+
+        Returns ``(bucket_keys, bucket_values_or_None, n_bucket)``: views into this
+        object's receive buffers holding this rank's range of the global result.
+        """
+        n = keys.numel() if n is None else int(n)
+        eng, W = self.engine, self.world
+        if W == 1:
+            self._recv[:n].copy_(keys[:n])
+            if values is not None:
+                self._recv_v[:n].copy_(values[:n])
+            eng.sort(self._recv, n, self._recv_v if values is not None else None)
+            return self._recv[:n], (self._recv_v[:n] if values is not None else None), n
+
+        # 1-2: histograms of every rank, splitters, split sizes
+        local = torch.from_numpy(eng.top_byte_histogram(keys, n)).to(self._gather.device)
+        dist.all_gather_into_tensor(self._gather, local, group=self.group)
+        table = self._gather.cpu().numpy().reshape(W, 256)          # [source, top byte]
+        first_bin = msd_splitters(table.sum(axis=0).astype(np.uint64), W)
+        csum = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(table, axis=1)], axis=1)
+        per_dest = csum[:, first_bin[1:]] - csum[:, first_bin[:-1]]  # [source, dest]
+        send = per_dest[self.rank].tolist()
+        recv = per_dest[:, self.rank].tolist()
+        n_recv = int(sum(recv))
+        self.last_counts = (send, recv)
+        if n_recv > self.capacity:
+            raise RuntimeError(f"rank {self.rank}: bucket of {n_recv} keys exceeds capacity {self.capacity}; "
+                               "input too skewed for a top-byte MSD split (raise slack)")
+        # 3: group by destination (stable)
+        eng.partition_by_top_byte(keys, self._part, n, values, self._part_v)
+        # 4: bucket exchange
+        dist.all_to_all_single(self._recv[:n_recv], self._part[:n], recv, send, group=self.group)
+        if values is not None:
+            dist.all_to_all_single(self._recv_v[:n_recv], self._part_v[:n], recv, send, group=self.group)
+        # 5: local sort
+        if n_recv:
+            eng.sort(self._recv, n_recv, self._recv_v if values is not None else None)
+        return self._recv[:n_recv], (self._recv_v[:n_recv] if values is not None else None), n_recv

@@ -1,0 +1,155 @@
+/*
+ * gpusort.h — C-ABI of the MI355X-native OneSweep radix sort (libgpusort.so).
+ *
+ * This is the drop-in boundary for the reference's OneSweep path
+ * (b0nes164/GPUSorting @ 2024_10_08).  The reference has no FFI: its boundary
+ * is a C++ class per backend.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference root).  On top of
+ * this header, include/gpusort/OneSweepDispatcher.hpp re-creates the CUDA
+ * tree's `OneSweepDispatcher` class verbatim (same method names, arguments
+ * and print format) so GPUSortingCUDA/GPUSortingCUDA.cu:20-23,36-39 compiles
+ * unchanged against it; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: streams are passed as void* (a hipStream_t;
+ *     NULL = the null stream); device pointers are void* and caller-owned.
+ *   - every call returns a gs_status; nothing throws across the boundary.
+ *   - all calls are asynchronous on `stream` unless stated otherwise.
+ *   - key/value device buffers must be 16-byte aligned.
+ *   - 1 <= n <= GS_MAX_KEYS (30-bit tile-descriptor payload, same limit as the
+ *     reference: GPUSortingCUDA/SegSort/SplitSort/SplitSortLarge.cuh:795-800).
+ *   - a handle serialises its sorts: one in-flight sort per handle (it owns the
+ *     chained-scan state).  Use one handle per stream.
+ */
+#ifndef GPUSORT_H
+#define GPUSORT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_MAX_KEYS ((1u << 30) - 1u)
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_ARG = 1,      /* NULL / misaligned pointer, bad enum */
+    GS_ERR_SIZE = 2,     /* n == 0, n > max_keys of the handle, n > GS_MAX_KEYS */
+    GS_ERR_HIP = 3,      /* a HIP runtime call failed (gs_last_hip_error() has the code) */
+    GS_ERR_TIMEOUT = 4,  /* a bounded look-back spin expired on the device */
+    GS_ERR_MODE = 5,     /* pairs call on a keys-only handle / value width mismatch */
+    GS_ERR_NO_DEVICE = 6 /* no gfx950 device visible */
+} gs_status;
+
+/* GPUSortingD3D12/GPUSorting.h:40-45 */
+typedef enum gs_mode { GS_MODE_KEYS_ONLY = 0, GS_MODE_PAIRS = 1 } gs_mode;
+/* GPUSortingD3D12/GPUSorting.h:47-52 */
+typedef enum gs_order { GS_ORDER_ASCENDING = 0, GS_ORDER_DESCENDING = 1 } gs_order;
+/* GPUSortingD3D12/GPUSorting.h:54-60 */
+typedef enum gs_key_type { GS_KEY_UINT32 = 0, GS_KEY_INT32 = 1, GS_KEY_FLOAT32 = 2 } gs_key_type;
+/* GPUSortingCUDA/UtilityKernels.cuh:16-24 (value = number of extra AND-ed draws) */
+typedef enum gs_entropy_preset {
+    GS_ENTROPY_PRESET_1 = 0, GS_ENTROPY_PRESET_2 = 1, GS_ENTROPY_PRESET_3 = 2,
+    GS_ENTROPY_PRESET_4 = 3, GS_ENTROPY_PRESET_5 = 4
+} gs_entropy_preset;
+
+typedef struct gs_onesweep gs_onesweep; /* opaque sorter state */
+
+const char* gs_version(void);
+const char* gs_status_string(gs_status s);
+int gs_last_hip_error(void); /* hipError_t of the last failing HIP call on this thread */
+
+/* ---- sorter object -------------------------------------------------------
+ * Replaces: OneSweepDispatcher::OneSweepDispatcher(bool keysOnly, uint32_t maxSize)
+ * / ~OneSweepDispatcher (GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:42-83) for
+ * the scan state (m_index, m_globalHistogram, m_*PassHistogram), and the temp
+ * buffers of Unity's OneSweep ctor (GPUSortingUnity/Runtime/OneSweep.cs:27-81).
+ * Key/value/alt buffers stay with the caller (Unity ownership model).
+ * value_bytes: 0 (keys only), 4 or 8.  Synchronous (allocates). */
+gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes);
+gs_status gs_onesweep_destroy(gs_onesweep* h);
+
+/* Bytes of device memory a handle for max_keys allocates (descriptors + histograms). */
+size_t gs_onesweep_temp_bytes(uint32_t max_keys);
+/* Keys per binning tile of this build (the reference's k_partitionSize = 7680,
+ * OneSweepDispatcher.cuh:23; tests ladder sizes over [P, 2P]). */
+uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes);
+
+/* ---- the hot path ---------------------------------------------------------
+ * Replaces: OneSweepDispatcher::DispatchKernelsKeysOnly(uint32_t size)
+ * (OneSweepDispatcher.cuh:311-336) and Unity OneSweep.Sort(...) keys overload
+ * (GPUSortingUnity/Runtime/OneSweep.cs:297-323).  Sorts d_keys[0..n) in place
+ * (result in d_keys, as in the reference after 4 passes); d_alt is scratch of
+ * n keys.  key_type/order as D3D12 GPUSortBase (GPUSortingD3D12/OneSweep.h:16-27). */
+gs_status gs_onesweep_sort_keys(gs_onesweep* h, void* d_keys, void* d_alt, uint32_t n,
+                                gs_key_type key_type, gs_order order, void* stream);
+
+/* Replaces: OneSweepDispatcher::DispatchKernelsPairs (OneSweepDispatcher.cuh:338-363)
+ * and Unity OneSweep.Sort pairs overload (OneSweep.cs:358-390).  Values are
+ * bit-copied (value_bytes of the handle); stable by key; descending = exact
+ * reverse of the stable ascending result (SortCommon.hlsl:594-597,645-656). */
+gs_status gs_onesweep_sort_pairs(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys,
+                                 void* d_alt_vals, uint32_t n, gs_key_type key_type,
+                                 gs_order order, void* stream);
+
+/* Synchronises `stream` and reads the device status word of the last sort:
+ * GS_OK or GS_ERR_TIMEOUT.  (The reference checks nothing; D3D12 only warns,
+ * GPUSortingD3D12/SweepBase.h:52-53.) */
+gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
+
+/* ---- tuning (no reference counterpart at run time; the reference fixes its
+ * tile shape with #defines, GPUSortingCUDA/Sort/OneSweep.cu:30-36, and the D3D12
+ * tree picks one per device in Tuner.h) -------------------------------------
+ * Select one of the compiled tile shapes (threads x keys-per-thread).  The
+ * default is what gs_onesweep_partition_size() reports.  Non-default shapes
+ * are compiled for uint32 keys only.  Env GPUSORT_SHAPE="TxK" sets it at create. */
+gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread);
+uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
+
+/* ---- structural entry points (parity tests, MSD split) --------------------
+ * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
+ * the four 256-bin histograms (counts, not prefixes) to h_hist[1024] on the
+ * host.  Synchronous. */
+gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint32_t n,
+                                       gs_key_type key_type, uint32_t* h_hist, void* stream);
+/* One stable DigitBinningPass (OneSweep.cu:164-344 / :346-600) on byte `pass`
+ * (0..3) from d_keys_in to d_keys_out (values optional, NULL for keys-only).
+ * reverse_index != 0 applies the reference's descending rule to this pass.
+ * Self-contained (clears state, histograms, scans, runs the one pass).  With
+ * pass = 3 this is the multi-GPU MSD partition step. */
+gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_keys_out,
+                                 const void* d_vals_in, void* d_vals_out, uint32_t n,
+                                 uint32_t pass, gs_key_type key_type, int reverse_index,
+                                 void* stream);
+
+/* ---- profiling hook --------------------------------------------------------
+ * Replaces the cudaEvent pair of BatchTiming* (OneSweepDispatcher.cuh:207-229)
+ * with per-kernel HIP events recorded on the sort's own stream.
+ * Slots: 0 state clear, 1 GlobalHistogram, 2 Scan, 3..6 DigitBinningPass 0..3, 7 whole sort. */
+#define GS_PROFILE_SLOTS 8
+gs_status gs_onesweep_set_profiling(gs_onesweep* h, int enabled);
+/* Synchronises the last profiled sort and returns milliseconds per slot. */
+gs_status gs_onesweep_get_profile(gs_onesweep* h, float ms[GS_PROFILE_SLOTS]);
+
+/* ---- fixtures exported for parity tests ------------------------------------
+ * Replaces: InitRandom<<<256,256>>> keys / pairs (GPUSortingCUDA/UtilityKernels.cuh:53-117).
+ * d_vals may be NULL; value_bytes 0/4/8 (value = key, zero-extended for 8). */
+gs_status gs_init_random(void* d_keys, void* d_vals, uint32_t value_bytes, uint32_t and_count,
+                         uint32_t seed, uint32_t n, void* stream);
+/* Replaces: Validate keys / pairs (UtilityKernels.cuh:402-479) + the 4-byte
+ * read-back of DispatchValidateKeys/Pairs (OneSweepDispatcher.cuh:365-391),
+ * order/type-aware as GPUSortingD3D12/Shaders/Utility.hlsl:147-230.
+ * Synchronous; *h_err_count = number of adjacent inversions. */
+gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_bytes, uint32_t n,
+                      gs_key_type key_type, gs_order order, uint32_t* h_err_count, void* stream);
+
+/* ---- multi-GPU MSD split helper (host only; no reference counterpart) ------
+ * From the all-reduced top-byte histogram pick the first top-byte bin each of
+ * `world` ranks owns: first_bin[0] = 0 ... first_bin[world] = 256. */
+gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t* first_bin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUSORT_H */

@@ -1,0 +1,76 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol
+include/gpusort.h declares; host-only entry points behave; no compute is run."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpusort.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"libgpusort.so does not export {name}"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes binding and header disagree"
+
+
+def test_version_and_status_strings():
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.gs_version()
+    assert lib.gs_status_string(0) == b"ok"
+    assert b"timeout" in lib.gs_status_string(_lib.GS_ERR_TIMEOUT)
+
+
+def test_argument_errors_without_touching_the_gpu():
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.gs_onesweep_create(None, 1024, 0, 0) == _lib.GS_ERR_ARG
+    assert lib.gs_onesweep_create(C.byref(h), 0, 0, 0) == _lib.GS_ERR_SIZE
+    assert lib.gs_onesweep_create(C.byref(h), 1 << 30, 0, 0) == _lib.GS_ERR_SIZE
+    assert lib.gs_onesweep_create(C.byref(h), 1024, 0, 4) == _lib.GS_ERR_MODE   # keys-only with values
+    assert lib.gs_onesweep_create(C.byref(h), 1024, 1, 2) == _lib.GS_ERR_MODE   # 2-byte values
+    assert lib.gs_onesweep_sort_keys(None, None, None, 4, 0, 0, None) == _lib.GS_ERR_ARG
+    assert lib.gs_onesweep_destroy(None) == _lib.GS_ERR_ARG
+    assert lib.gs_onesweep_temp_bytes(1 << 28) > 0
+    assert lib.gs_onesweep_partition_size(0, 0) % 64 == 0
+
+
+def test_msd_splitters_match_oracle(oracle):
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 4, 8):
+        for hist in (np.full(256, 12345, dtype=np.uint64), rng.integers(0, 10**6, 256).astype(np.uint64),
+                     np.concatenate([np.full(8, 10**7), np.zeros(248)]).astype(np.uint64)):
+            fb = (C.c_uint32 * (world + 1))()
+            st = lib.gs_msd_splitters(hist.ctypes.data_as(C.POINTER(C.c_uint64)), world, fb)
+            assert st == 0
+            assert list(fb) == oracle.msd_splitters(hist, world).tolist()
+    assert lib.gs_msd_splitters(None, 2, None) == _lib.GS_ERR_ARG
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never route through oracle/ (prompt rule 3)."""
+    pkg = os.path.join(ROOT, "gpusorting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "gs_oracle" not in src and "oracle_lib" not in src and "gso_" not in src, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        p = os.path.join(ROOT, "include", f)
+        if os.path.isfile(p):
+            assert "gso_" not in open(p).read()

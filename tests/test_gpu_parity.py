@@ -1,0 +1,255 @@
+"""GPU parity tests (-m gpu): the HIP path through the C-ABI vs the CPU oracle,
+bit-exact (integer/byte/index work: no tolerance)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "onesweep_golden.npz")
+_NP_KEY = {0: np.uint32, 1: np.int32, 2: np.float32}
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def to_dev(a):
+    import torch
+    if a.dtype == np.uint64:
+        return torch.from_numpy(a.view(np.int64)).cuda()
+    return torch.from_numpy(a.view(np.int32)).cuda()
+
+
+def to_host(t, dtype):
+    return t.cpu().numpy().view(dtype)
+
+
+@pytest.fixture(scope="module")
+def P(gpu):
+    s = gpu.OneSweep(1 << 16)
+    p = s.partition_size
+    s.close()
+    return p
+
+
+def _gpu_sort(gpu, keys, kt=0, order=0, vals=None, max_keys=None):
+    mode = gpu.MODE_KEYS_ONLY if vals is None else gpu.MODE_PAIRS
+    vb = 0 if vals is None else vals.dtype.itemsize
+    s = gpu.OneSweep(max_keys or max(keys.size, 1), order, kt, mode, vb)
+    dk = to_dev(keys)
+    dv = None if vals is None else to_dev(vals)
+    s.sort(dk, dv)
+    s.check()
+    out = to_host(dk, np.uint32), (None if vals is None else to_host(dv, vals.dtype))
+    s.close()
+    return out
+
+
+def test_init_random_parity(gpu, oracle):
+    import torch
+    for n, seed, andc, vb in [(1, 1, 0, 0), (63, 2, 0, 4), (65536, 10, 0, 0), (65537, 10, 1, 8), (200003, 77, 4, 4),
+                              (1 << 20, 26, 0, 0)]:
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        dv = None if not vb else torch.empty(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
+        gpu.init_random(dk, seed, andc, dv)
+        torch.cuda.synchronize()
+        ref = oracle.init_random(n, seed, andc, vb)
+        rk, rv = (ref, None) if not vb else ref
+        np.testing.assert_array_equal(to_host(dk, np.uint32), rk)
+        if vb:
+            np.testing.assert_array_equal(to_host(dv, rv.dtype), rv)
+
+
+@pytest.mark.parametrize("kt", [0, 1, 2])
+def test_global_histogram_parity(gpu, oracle, kt):
+    for n in (1, 3, 4, 5, 1023, 65536, 65539, (1 << 22) + 1):
+        keys = oracle.init_random(n, n + 1, 0)
+        s = gpu.OneSweep(n, key_type=kt)
+        h = s.global_histogram(to_dev(keys))
+        s.close()
+        np.testing.assert_array_equal(h, oracle.global_histogram(keys, kt), err_msg=f"n={n}")
+
+
+@pytest.mark.parametrize("vb", [0, 4, 8])
+def test_each_digit_pass_parity(gpu, oracle, P, vb):
+    import torch
+    for n in (100, P, P + 1, 3 * P + 17, (1 << 20) + 5):
+        keys = oracle.init_random(n, n, 1)
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        dk = to_dev(keys)
+        dv = None if not vb else to_dev(vals)
+        for p in range(4):
+            for rev in (False, True):
+                ok = torch.zeros_like(dk)
+                ov = None if not vb else torch.zeros_like(dv)
+                s.digit_pass(dk, ok, p, values_in=dv, values_out=ov, reverse_index=rev)
+                s.check()
+                ref = oracle.digit_pass(keys, 8 * p, 0, vals, rev)
+                rk, rv = (ref, None) if not vb else ref
+                np.testing.assert_array_equal(to_host(ok, np.uint32), rk, err_msg=f"n={n} pass={p} rev={rev}")
+                if vb:
+                    np.testing.assert_array_equal(to_host(ov, vals.dtype), rv, err_msg=f"vals n={n} pass={p}")
+        s.close()
+
+
+def _size_ladder(P):
+    small = [1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 1000, 4095, 4096, 4097]
+    around = [P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 3 * P + 1]
+    ladder = list(range(P, 2 * P + 1, 509))
+    big = [65536, 100003, (1 << 20) + 3]
+    return sorted(set(small + around + ladder + big))
+
+
+def test_keys_sort_parity_size_ladder(gpu, oracle, P):
+    """Reference test shape: every partial-tile remainder class in [P, 2P] (OneSweepDispatcher.cuh:98-113), seed = size."""
+    s = gpu.OneSweep((1 << 20) + 3)
+    for n in _size_ladder(P):
+        keys = oracle.init_random(n, n, 0)
+        dk = to_dev(keys)
+        s.sort(dk)
+        s.check()
+        np.testing.assert_array_equal(to_host(dk, np.uint32), oracle.std_sort(keys), err_msg=f"n={n}")
+    s.close()
+
+
+@pytest.mark.parametrize("kt", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1])
+def test_key_types_and_orders(gpu, oracle, P, kt, order):
+    """D3D12 SuperTestOneSweep matrix, keys (Tests.h:6-186): {asc,desc} x {uint,int,float}."""
+    for n in (2, 1000, P + 7, 65536, 300001):
+        keys = oracle.init_random(n, 5 + n, 0)
+        out, _ = _gpu_sort(gpu, keys, kt, order)
+        np.testing.assert_array_equal(out, oracle.std_sort(keys, kt, order), err_msg=f"n={n}")
+        assert oracle.validate(out, kt, order) == 0
+
+
+@pytest.mark.parametrize("vb", [4, 8])
+@pytest.mark.parametrize("kt,order", [(0, 0), (0, 1), (1, 0), (2, 1)])
+def test_pairs_parity_and_stability(gpu, oracle, P, vb, kt, order):
+    """value = original index exposes stability; duplicates forced with entropy preset 4."""
+    for n, andc in ((1, 0), (65, 3), (P, 0), (P + 1, 3), (2 * P + 3, 0), (250007, 3), ((1 << 20) + 3, 0)):
+        keys = oracle.init_random(n, 11 + n, andc)
+        vals = np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ok, ov = _gpu_sort(gpu, keys, kt, order, vals)
+        rk, rv = oracle.std_sort(keys, kt, order, vals)
+        np.testing.assert_array_equal(ok, rk, err_msg=f"keys n={n}")
+        np.testing.assert_array_equal(ov, rv, err_msg=f"values n={n}")
+
+
+def test_pairs_reference_payload_convention(gpu, oracle, P):
+    """The reference's own pairs check: payload := key, both must come out sorted (UtilityKernels.cuh:432-479)."""
+    import torch
+    n = 3 * P + 5
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    dv = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, n, 0, dv)
+    s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS, value_bytes=4)
+    s.sort(dk, dv)
+    s.check()
+    assert gpu.validate(dk, dv) == 0
+    np.testing.assert_array_equal(to_host(dk, np.uint32), to_host(dv, np.uint32))
+    s.close()
+
+
+@pytest.mark.parametrize("andc", [0, 1, 2, 3, 4])
+def test_entropy_presets_u64_values(gpu, oracle, andc):
+    """BASELINE config 5 at test size: (u32 key, u64 value) under the 5 Thearling-Smith presets."""
+    n = (1 << 19) + 1
+    keys = oracle.init_random(n, 10, andc)
+    vals = np.arange(n, dtype=np.uint64) * np.uint64(0x100000001)
+    ok, ov = _gpu_sort(gpu, keys, 0, 0, vals)
+    rk, rv = oracle.std_sort(keys, 0, 0, vals)
+    np.testing.assert_array_equal(ok, rk)
+    np.testing.assert_array_equal(ov, rv)
+
+
+def test_degenerate_distributions(gpu, oracle, P):
+    n = 2 * P + 100
+    for keys in (np.zeros(n, np.uint32), np.full(n, 0xFFFFFFFF, np.uint32), np.arange(n, dtype=np.uint32)[::-1].copy(),
+                 (np.arange(n, dtype=np.uint32) % 3) << 24, np.arange(n, dtype=np.uint32)):
+        vals = np.arange(n, dtype=np.uint32)
+        ok, ov = _gpu_sort(gpu, keys, 0, 0, vals)
+        rk, rv = oracle.std_sort(keys, 0, 0, vals)
+        np.testing.assert_array_equal(ok, rk)
+        np.testing.assert_array_equal(ov, rv)
+
+
+def test_golden_vectors_on_gpu(gpu):
+    g = np.load(GOLDEN)
+    import torch
+    for ci, row in enumerate(g["cases"]):
+        n, seed, andc, kt, order, vb = (int(x) for x in row)
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, seed, andc)
+        torch.cuda.synchronize()
+        keys = to_host(dk, np.uint32).copy()
+        assert crc(keys) == int(g[f"c{ci}_in_crc"]), f"generator case {ci}"
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ok, ov = _gpu_sort(gpu, keys, kt, order, vals)
+        assert crc(ok) == int(g[f"c{ci}_out_crc"]), f"sort case {ci}"
+        np.testing.assert_array_equal(ok[:16], g[f"c{ci}_out_head"])
+        if vb:
+            assert crc(ov) == int(g[f"c{ci}_vout_crc"]), f"values case {ci}"
+
+
+def test_handle_reuse_and_caller_owned_alt(gpu, oracle, P):
+    """One handle, many sizes, caller-provided temp buffers (Unity Sort signature, OneSweep.cs:297-323)."""
+    import torch
+    s = gpu.OneSweep(1 << 18)
+    alt = torch.empty(1 << 18, dtype=torch.int32, device="cuda")
+    for n in (1 << 18, 17, P + 3, 1 << 18, 1):
+        keys = oracle.init_random(n, 1000 + n, 0)
+        dk = to_dev(keys)
+        s.sort(dk, alt_keys=alt)
+        s.check()
+        np.testing.assert_array_equal(to_host(dk, np.uint32), np.sort(keys))
+    s.close()
+
+
+def test_error_behaviour(gpu):
+    import torch
+    s = gpu.OneSweep(1000)
+    k = torch.zeros(2000, dtype=torch.int32, device="cuda")
+    with pytest.raises(gpu.GpuSortError) as e:
+        s.sort(k, n=1001)
+    assert e.value.status == 2  # GS_ERR_SIZE
+    with pytest.raises(gpu.GpuSortError) as e:
+        s.sort(k, n=0)
+    assert e.value.status == 2
+    with pytest.raises(gpu.GpuSortError) as e:
+        s.sort(k[1:], n=10)  # misaligned (4-byte offset)
+    assert e.value.status == 1  # GS_ERR_ARG
+    with pytest.raises(ValueError):
+        s.sort(k, k.clone(), n=10)  # values on a keys-only sorter
+    s.close()
+
+
+def test_dispatcher_quick(gpu):
+    """OneSweepDispatcher::TestAllKeysOnly / TestAllPairs at CI size (quick ladder)."""
+    lines = []
+    d = gpu.OneSweepDispatcher(True, 1 << 20, out=lines.append)
+    assert d.TestAllKeysOnly(quick=True), lines
+    d2 = gpu.OneSweepDispatcher(False, 1 << 20, out=lines.append)
+    assert d2.TestAllPairs(quick=True), lines
+    assert any("All tests passed" in l for l in lines)
+
+
+def test_every_compiled_shape(gpu, oracle):
+    for t, k in ((512, 16), (256, 16), (512, 8), (1024, 8), (256, 32), (512, 32), (1024, 16)):
+        s = gpu.OneSweep(1 << 20)
+        try:
+            s.set_shape(t, k)
+        except gpu.GpuSortError:
+            s.close()
+            continue
+        for n in (t * k + 1, (1 << 20) - 5):
+            keys = oracle.init_random(n, n, 0)
+            dk = to_dev(keys)
+            s.sort(dk)
+            s.check()
+            np.testing.assert_array_equal(to_host(dk, np.uint32), np.sort(keys), err_msg=f"{t}x{k} n={n}")
+        s.close()

@@ -1,0 +1,140 @@
+"""CPU tests: the oracle against the golden vectors and against itself (no GPU)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "onesweep_golden.npz")
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def _cases(golden):
+    return [tuple(int(x) for x in row) for row in golden["cases"]]
+
+
+def test_generator_matches_golden(oracle, golden):
+    for ci, (n, seed, andc, kt, order, vb) in enumerate(_cases(golden)):
+        keys = oracle.init_random(n, seed, andc)
+        assert crc(keys) == int(golden[f"c{ci}_in_crc"]), f"case {ci}"
+        np.testing.assert_array_equal(keys[:16], golden[f"c{ci}_in_head"])
+        if f"c{ci}_in" in golden:
+            np.testing.assert_array_equal(keys, golden[f"c{ci}_in"])
+
+
+def test_generator_values_equal_keys(oracle):
+    k, v = oracle.init_random(70000, 9, 1, value_bytes=4)
+    np.testing.assert_array_equal(k, v)
+    k, v = oracle.init_random(70000, 9, 1, value_bytes=8)
+    np.testing.assert_array_equal(k.astype(np.uint64), v)
+
+
+def test_sorts_match_golden(oracle, golden):
+    for ci, (n, seed, andc, kt, order, vb) in enumerate(_cases(golden)):
+        keys = oracle.init_random(n, seed, andc)
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        for fn in (oracle.std_sort, oracle.onesweep_sort):
+            r = fn(keys, kt, order, vals)
+            sk, sv = (r, None) if vals is None else r
+            assert crc(sk) == int(golden[f"c{ci}_out_crc"]), f"case {ci} {fn.__name__}"
+            np.testing.assert_array_equal(sk[-16:], golden[f"c{ci}_out_tail"])
+            if vb:
+                assert crc(sv) == int(golden[f"c{ci}_vout_crc"]), f"case {ci} {fn.__name__} values"
+            if f"c{ci}_out" in golden:
+                np.testing.assert_array_equal(sk, golden[f"c{ci}_out"])
+
+
+def test_entropy_presets_reduce_popcount(oracle):
+    # Thearling-Smith: AND-ing k+1 uniform words leaves bit density 2^-(k+1)
+    for andc, dens in enumerate((0.5, 0.25, 0.125, 0.0625, 0.03125)):
+        k = oracle.init_random(1 << 16, 10, andc)
+        ones = np.unpackbits(k.view(np.uint8)).mean()
+        assert abs(ones - dens) < 0.01
+
+
+@pytest.mark.parametrize("kt", [0, 1, 2])
+def test_key_transform_is_order_preserving(oracle, kt):
+    rng = np.random.default_rng(kt)
+    raw = rng.integers(0, 1 << 32, size=4096, dtype=np.uint64).astype(np.uint32)
+    if kt == 2:
+        f = raw.view(np.float32)
+        raw = raw[np.isfinite(f)]
+    bits = np.array([oracle.lib.gso_key_to_bits(int(x), kt) for x in raw], dtype=np.uint32)
+    back = np.array([oracle.lib.gso_bits_to_key(int(x), kt) for x in bits], dtype=np.uint32)
+    np.testing.assert_array_equal(back, raw)
+    native = raw if kt == 0 else raw.view(np.int32) if kt == 1 else raw.view(np.float32)
+    order_native = np.argsort(native, kind="stable")
+    order_bits = np.argsort(bits, kind="stable")
+    # -0.0 < +0.0 in bit order but equal as floats: compare values, not permutations
+    np.testing.assert_array_equal(native[order_native] == native[order_bits], True)
+
+
+def test_structural_passes(oracle):
+    keys = oracle.init_random(20000, 77, 0)
+    hist = oracle.global_histogram(keys)
+    assert hist.sum(axis=1).tolist() == [20000] * 4
+    excl = oracle.scan(hist)
+    np.testing.assert_array_equal(excl, np.cumsum(hist, axis=1) - hist)
+    cur = keys
+    for p in range(4):
+        cur = oracle.digit_pass(cur, 8 * p)
+        d = (cur >> (8 * p)) & 255
+        assert np.all(d[:-1] <= d[1:])
+    np.testing.assert_array_equal(cur, np.sort(keys))
+
+
+def test_descending_is_reverse_of_stable_ascending(oracle):
+    keys = oracle.init_random(5000, 3, 3)  # many duplicates
+    vals = np.arange(5000, dtype=np.uint32)
+    ak, av = oracle.onesweep_sort(keys, 0, 0, vals)
+    dk, dv = oracle.onesweep_sort(keys, 0, 1, vals)
+    np.testing.assert_array_equal(dk, ak[::-1])
+    np.testing.assert_array_equal(dv, av[::-1])
+    sk, sv = oracle.std_sort(keys, 0, 1, vals)
+    np.testing.assert_array_equal(sk, dk)
+    np.testing.assert_array_equal(sv, dv)
+
+
+def test_validate_counts_inversions(oracle):
+    a = np.array([1, 2, 2, 5, 4, 9, 8, 8], dtype=np.uint32)
+    assert oracle.validate(a) == 2
+    assert oracle.validate(np.sort(a)) == 0
+    assert oracle.validate(np.sort(a)[::-1].copy(), order=1) == 0
+    assert oracle.validate(np.sort(a), vals=np.sort(a)) == 0
+    f = np.array([-1.5, -0.0, 0.0, 3.0], dtype=np.float32).view(np.uint32)
+    assert oracle.validate(f, key_type=2) == 0
+    assert oracle.validate(f) != 0  # as raw uint32 the negatives sort last
+
+
+def test_config1_2pow16_host_path(oracle):
+    """BASELINE.json configs[0]: 2^16 uint32 keys, host std::sort validation path (no GPU)."""
+    keys = oracle.init_random(1 << 16, 10, 0)
+    s = oracle.std_sort(keys)
+    assert oracle.validate(s) == 0
+    np.testing.assert_array_equal(s, np.sort(keys))
+    np.testing.assert_array_equal(oracle.onesweep_sort(keys), s)
+    np.testing.assert_array_equal(oracle.std_sort_parallel(keys, 4), s)
+
+
+def test_parallel_sort(oracle):
+    keys = oracle.init_random((1 << 18) + 11, 5, 0)
+    for t in (1, 2, 3, 8):
+        np.testing.assert_array_equal(oracle.std_sort_parallel(keys, t), np.sort(keys))
+
+
+def test_msd_splitters(oracle):
+    uni = np.full(256, 1000, dtype=np.uint64)
+    assert oracle.msd_splitters(uni, 8).tolist() == [0, 32, 64, 96, 128, 160, 192, 224, 256]
+    assert oracle.msd_splitters(uni, 1).tolist() == [0, 256]
+    skew = np.zeros(256, dtype=np.uint64)
+    skew[0] = 10**6
+    fb = oracle.msd_splitters(skew, 4)
+    assert fb[0] == 0 and fb[-1] == 256 and np.all(np.diff(fb.astype(np.int64)) >= 0)

@@ -1,0 +1,111 @@
+"""world_size-2 (and 3) gloo test of the multi-GPU control flow on CPU.
+
+The product's ShardedOneSweep is run unchanged; only the per-rank engine is
+replaced by an oracle-backed CPU engine (test infrastructure), so the splitter
+logic, count exchange, all-to-all-v layout and result ordering are covered."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+class OracleEngine:
+    device = torch.device("cpu")
+
+    def __init__(self):
+        sys.path.insert(0, HERE)
+        import oracle_lib
+        self.o = oracle_lib.load()
+
+    @staticmethod
+    def _np(t, n):
+        return t[:n].numpy().view(np.uint32 if t.dtype == torch.int32 else np.uint64)
+
+    def empty_like_keys(self, n):
+        return torch.empty(n, dtype=torch.int32)
+
+    def top_byte_histogram(self, keys, n):
+        return self.o.global_histogram(np.ascontiguousarray(self._np(keys, n)))[3].astype(np.int64)
+
+    def partition_by_top_byte(self, keys, out, n, values=None, values_out=None):
+        k = np.ascontiguousarray(self._np(keys, n))
+        if values is None:
+            self._np(out, n)[:] = self.o.digit_pass(k, 24)
+        else:
+            ko, vo = self.o.digit_pass(k, 24, vals=np.ascontiguousarray(self._np(values, n)))
+            self._np(out, n)[:] = ko
+            self._np(values_out, n)[:] = vo
+
+    def sort(self, keys, n, values=None):
+        k = np.ascontiguousarray(self._np(keys, n))
+        if values is None:
+            self._np(keys, n)[:] = self.o.std_sort(k)
+        else:
+            ko, vo = self.o.std_sort(k, vals=np.ascontiguousarray(self._np(values, n)))
+            self._np(keys, n)[:] = ko
+            self._np(values, n)[:] = vo
+
+    def synchronize(self):
+        pass
+
+
+def _worker(rank, world, port, shard, andc, pairs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle_lib
+    from gpusorting_amd.sharded import ShardedOneSweep
+    o = oracle_lib.load()
+    keys = o.init_random(shard, 10 + 1000 * rank, andc)
+    vals = (np.arange(shard, dtype=np.uint32) + np.uint32(rank * shard)) if pairs else None
+    s = ShardedOneSweep(shard, engine=OracleEngine(), slack=4.0, pairs=pairs, value_bytes=4)
+    tk = torch.from_numpy(keys.view(np.int32).copy())
+    tv = torch.from_numpy(vals.view(np.int32).copy()) if pairs else None
+    bk, bv, nb = s.sort(tk, values=tv)
+    q.put((rank, keys, vals, bk.numpy().view(np.uint32).copy(), None if bv is None else bv.numpy().view(np.uint32).copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,andc,pairs", [(2, 0, False), (2, 0, True), (3, 0, False), (2, 2, True)])
+def test_sharded_sort_gloo(world, andc, pairs):
+    shard = 20011
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([g[1] for g in got])
+    out_keys = np.concatenate([g[3] for g in got])
+    if not pairs:
+        np.testing.assert_array_equal(out_keys, np.sort(all_keys))
+    else:
+        all_vals = np.concatenate([g[2] for g in got])
+        out_vals = np.concatenate([g[4] for g in got])
+        perm = np.argsort(all_keys, kind="stable")  # global stable order: (rank, position)
+        np.testing.assert_array_equal(out_keys, all_keys[perm])
+        np.testing.assert_array_equal(out_vals, all_vals[perm])
+    # buckets are contiguous ranges: max of rank r <= min of rank r+1
+    for a, b in zip(got[:-1], got[1:]):
+        if a[3].size and b[3].size:
+            assert a[3].max() <= b[3].min()
