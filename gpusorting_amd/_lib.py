@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpusort.so")
+LIB_PATH = os.environ.get("GPUSORT_LIB") or os.path.join(_HERE, "lib", "libgpusort.so")  # env: ablation builds
 
 GS_OK, GS_ERR_ARG, GS_ERR_SIZE, GS_ERR_HIP, GS_ERR_TIMEOUT, GS_ERR_MODE, GS_ERR_NO_DEVICE = range(7)
 GS_MAX_KEYS = (1 << 30) - 1
@@ -32,6 +32,10 @@ _PROTOS = [
     ("gs_onesweep_check", _int, [_vp, _vp]),
     ("gs_onesweep_set_shape", _int, [_vp, _u32, _u32]),
     ("gs_onesweep_get_partition_size", _u32, [_vp]),
+    ("gs_onesweep_set_rank_mode", _int, [_vp, _int]),
+    ("gs_onesweep_set_persistent", _int, [_vp, _int]),
+    ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
+    ("gs_debug_copy_floor", _int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
     ("gs_onesweep_set_profiling", _int, [_vp, _int]),

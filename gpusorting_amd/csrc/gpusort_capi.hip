@@ -37,34 +37,66 @@ using BinLauncher = void (*)(hipStream_t, uint32_t tiles, const uint32_t*, uint3
                              uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
                              uint32_t reverse);
 
-template <int THREADS, int KPT, int VB, int KT>
+template <int THREADS, int KPT, int VB, int KT, int RANK>
 void launch_bin(hipStream_t s, uint32_t tiles, const uint32_t* kin, uint32_t* kout, const void* vin, void* vout,
                 uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
                 uint32_t reverse) {
-    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT>), dim3(tiles), dim3(THREADS), 0, s, kin,
+    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(tiles + (GS_LB ? gs::NSCAN_WAVES / (THREADS / 64) : 0u)), dim3(THREADS), 0, s, kin,
+                       kout, vin, vout, desc, counter, status, n, shift, reverse);
+}
+
+// persistent, software-pipelined form: grid = resident workgroups (occupancy x CUs), each loops over tickets
+template <int THREADS, int KPT, int VB, int KT, int RANK>
+void launch_bin_persistent(hipStream_t s, uint32_t tiles, const uint32_t* kin, uint32_t* kout, const void* vin,
+                           void* vout, uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
+                           uint32_t reverse) {
+    static int resident = 0;  // per instantiation
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &per_cu, gs::digit_binning_persistent<THREADS, KPT, VB, KT, RANK>, THREADS, 0) == hipSuccess &&
+            per_cu > 0)
+            resident = per_cu * prop.multiProcessorCount;
+        else
+            resident = 256;
+    }
+    const uint32_t grid = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
+    hipLaunchKernelGGL((gs::digit_binning_persistent<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, kin,
                        kout, vin, vout, desc, counter, status, n, shift, reverse);
 }
 
 struct Shape {
     int threads, kpt;
-    BinLauncher fn[3][3];  // [vb index 0/4/8][key type]; nullptr = not compiled
+    BinLauncher fn[2][3][3];   // one tile per workgroup: [rank mode][vb index 0/4/8][key type]; nullptr = not compiled
+    BinLauncher fnp[2][3][3];  // persistent pipelined form
 };
 
-#define GS_FULL(T, K)                                                                              \
-    {                                                                                              \
-        T, K, {                                                                                    \
-            {launch_bin<T, K, 0, 0>, launch_bin<T, K, 0, 1>, launch_bin<T, K, 0, 2>},              \
-                {launch_bin<T, K, 4, 0>, launch_bin<T, K, 4, 1>, launch_bin<T, K, 4, 2>},          \
-                {launch_bin<T, K, 8, 0>, launch_bin<T, K, 8, 1>, launch_bin<T, K, 8, 2>},          \
-        }                                                                                          \
+#define GS_ROWS(T, K, R)                                                                             \
+    {                                                                                                \
+        {launch_bin<T, K, 0, 0, R>, launch_bin<T, K, 0, 1, R>, launch_bin<T, K, 0, 2, R>},           \
+            {launch_bin<T, K, 4, 0, R>, launch_bin<T, K, 4, 1, R>, launch_bin<T, K, 4, 2, R>},       \
+            {launch_bin<T, K, 8, 0, R>, launch_bin<T, K, 8, 1, R>, launch_bin<T, K, 8, 2, R>},       \
     }
-#define GS_U32ONLY(T, K)                                                                           \
-    {                                                                                              \
-        T, K, {                                                                                    \
-            {launch_bin<T, K, 0, 0>, nullptr, nullptr}, {launch_bin<T, K, 4, 0>, nullptr, nullptr}, \
-                {launch_bin<T, K, 8, 0>, nullptr, nullptr},                                        \
-        }                                                                                          \
+#define GS_ROWS_U32(T, K, R)                                                                         \
+    {                                                                                                \
+        {launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin<T, K, 4, 0, R>, nullptr, nullptr}, \
+            {launch_bin<T, K, 8, 0, R>, nullptr, nullptr},                                           \
     }
+#define GS_PROWS(T, K, R)                                                                            \
+    {                                                                                                \
+        {launch_bin_persistent<T, K, 0, 0, R>, launch_bin_persistent<T, K, 0, 1, R>, launch_bin_persistent<T, K, 0, 2, R>}, \
+            {launch_bin_persistent<T, K, 4, 0, R>, launch_bin_persistent<T, K, 4, 1, R>, launch_bin_persistent<T, K, 4, 2, R>}, \
+            {launch_bin_persistent<T, K, 8, 0, R>, launch_bin_persistent<T, K, 8, 1, R>, launch_bin_persistent<T, K, 8, 2, R>}, \
+    }
+#define GS_PROWS_U32(T, K, R)                                                                        \
+    {                                                                                                \
+        {launch_bin_persistent<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin_persistent<T, K, 4, 0, R>, nullptr, nullptr}, \
+            {launch_bin_persistent<T, K, 8, 0, R>, nullptr, nullptr},                                \
+    }
+#define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}, {GS_PROWS(T, K, 0), GS_PROWS(T, K, 1)}}
+#define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}, {GS_PROWS_U32(T, K, 0), GS_PROWS_U32(T, K, 1)}}
 
 const Shape g_shapes[] = {
     GS_FULL(512, 16),  // default
@@ -94,12 +126,15 @@ struct gs_onesweep {
     gs_mode mode;
     uint32_t value_bytes;
     int shape;
+    int persistent; // 1 = persistent software-pipelined DigitBinningPass (default), 0 = one tile per workgroup
+    int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
     int profiling;
     hipEvent_t ev[GS_PROFILE_SLOTS + 1];
     bool ev_valid;
     bool profile_pending;
+    void* trace_buf;   // experiment builds only (GS_EXP & 2)
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
 };
 
@@ -107,7 +142,7 @@ namespace {
 
 size_t slab_words_for(uint32_t max_keys) {
     const size_t max_tiles = div_up(max_keys, MIN_TILE);
-    return SLAB_DESC + 4 * (max_tiles + 1) * (size_t)gs::RADIX;
+    return SLAB_DESC + 4 * 2 * (max_tiles + 1) * (size_t)gs::RADIX;
 }
 
 using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
@@ -132,14 +167,18 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const Shape& sh = g_shapes[h->shape];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
-    const uint32_t desc_stride = (tiles + 1) * gs::RADIX;
+    const uint32_t desc_stride = 2 * (tiles + 1) * gs::RADIX;  // two slice-major arrays of tiles+1 rows
     const size_t used_words = SLAB_DESC + 4 * (size_t)desc_stride;
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     GS_HIP(hipMemsetAsync(h->slab, 0, used_words * sizeof(uint32_t), s));
+#if (GS_EXP & 2)
+    GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 4, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
+#endif
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_GHIST, n);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL(gs::scan_kernel, dim3(4), dim3(256), 0, s, h->slab + SLAB_GHIST, h->slab + SLAB_DESC, desc_stride);
+    hipLaunchKernelGGL(gs::scan_kernel, dim3(4), dim3(256), 0, s, h->slab + SLAB_GHIST, h->slab + SLAB_DESC, desc_stride,
+                       (uint32_t)((GS_LB && !h->persistent) ? 1u : 0u));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
     *tiles_out = tiles;
     *desc_stride_out = desc_stride;
@@ -156,7 +195,7 @@ gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n,
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
     const Shape& sh = g_shapes[h->shape];
-    BinLauncher fn = sh.fn[vb_index(vb)][kt];
+    BinLauncher fn = (h->persistent ? sh.fnp : sh.fn)[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     uint32_t tiles = 0, desc_stride = 0;
     gs_status st = prologue(h, d_keys, n, kt, s, &tiles, &desc_stride);
@@ -174,6 +213,22 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     return GS_OK;
 }
 
+}  // namespace
+
+extern "C" gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
+
+namespace {
+bool lds_atomic_order_ok() {
+    static int cached[64];  // per device: 0 unknown, 1 ok, 2 failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (cached[dev] == 0) {
+        uint64_t fails = 1;
+        const gs_status st = gs_selftest_lds_atomic_order(64, 0x9e3779b9u, &fails, nullptr);
+        cached[dev] = (st == GS_OK && fails == 0) ? 1 : 2;
+    }
+    return cached[dev] == 1;
+}
 }  // namespace
 
 extern "C" {
@@ -220,12 +275,21 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->mode = mode;
     h->value_bytes = value_bytes;
     h->shape = 0;
+    h->rank_mode = 0;
+    h->persistent = 1;
+    if (const char* env = getenv("GPUSORT_PERSISTENT")) h->persistent = atoi(env) ? 1 : 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
     h->slab = nullptr;
     h->pinned = nullptr;
+    h->trace_buf = nullptr;
     h->slab_words = slab_words_for(max_keys);
+    // Tile ranking: the returning-LDS-atomic path needs same-address lanes of one
+    // wave-instruction served in ascending lane order.  Probe the device once per
+    // process; fall back to the ballot multi-split if a single lane disagrees.
+    h->rank_mode = lds_atomic_order_ok() ? 1 : 0;
+    if (const char* env = getenv("GPUSORT_RANK")) h->rank_mode = atoi(env) == 1 ? 1 : 0;
     if (const char* env = getenv("GPUSORT_SHAPE")) {  // e.g. "512x16"
         int t = 0, k = 0;
         if (sscanf(env, "%dx%d", &t, &k) == 2)
@@ -262,6 +326,57 @@ gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_
             return GS_OK;
         }
     return GS_ERR_ARG;
+}
+
+gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment builds: 4 * tiles * 8 words
+    if (!h) return GS_ERR_ARG;
+    h->trace_buf = d_buf;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_persistent(gs_onesweep* h, int on) {
+    if (!h) return GS_ERR_ARG;
+    h->persistent = on ? 1 : 0;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return GS_ERR_ARG;
+    h->rank_mode = mode;
+    return GS_OK;
+}
+
+gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream) {
+    if (!h_failures || iters == 0) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* d = nullptr;
+    GS_HIP(hipMalloc(&d, sizeof(uint32_t)));
+    gs_status ret = GS_OK;
+    uint32_t h32 = 0;
+    if (hipMemsetAsync(d, 0, sizeof(uint32_t), s) != hipSuccess) ret = GS_ERR_HIP;
+    if (ret == GS_OK) {
+        hipLaunchKernelGGL(gs::lds_atomic_order_probe, dim3(256 * 4), dim3(512), 0, s, seed, iters, d);
+        if (hipMemcpyAsync(&h32, d, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            ret = GS_ERR_HIP;
+    }
+    (void)hipFree(d);
+    *h_failures = h32;
+    return ret;
+}
+
+gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads, uint32_t kpt, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t tiles = n / (threads * kpt);
+    if (!tiles) return GS_ERR_SIZE;
+    const uint32_t* in = static_cast<const uint32_t*>(d_in);
+    uint32_t* out = static_cast<uint32_t*>(d_out);
+    if (threads == 512 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<512, 16>), dim3(tiles), dim3(512), 0, s, in, out, n);
+    else if (threads == 1024 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<1024, 16>), dim3(tiles), dim3(1024), 0, s, in, out, n);
+    else if (threads == 256 && kpt == 32) hipLaunchKernelGGL((gs::copy_floor_kernel<256, 32>), dim3(tiles), dim3(256), 0, s, in, out, n);
+    else return GS_ERR_ARG;
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h) {
@@ -320,7 +435,7 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
         vb = h->value_bytes;
     }
     const Shape& sh = g_shapes[h->shape];
-    BinLauncher fn = sh.fn[vb_index(vb)][kt];
+    BinLauncher fn = (h->persistent ? sh.fnp : sh.fn)[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint32_t tiles, stride;

@@ -106,6 +106,21 @@ gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
  * are compiled for uint32 keys only.  Env GPUSORT_SHAPE="TxK" sets it at create. */
 gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread);
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
+/* Ranking algorithm inside a tile: 0 = 64-lane ballot multi-split (the
+ * reference's WLMS, OneSweep.cu:207-253, re-derived for wave64); 1 = one
+ * returning LDS atomic per key, valid only if gs_selftest_lds_atomic_order()
+ * reports 0 failures on this device. */
+gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
+/* DigitBinningPass form: 1 = persistent software-pipelined workgroups (default),
+ * 0 = one tile per workgroup (the reference's launch shape, OneSweepDispatcher.cuh:325-335). */
+gs_status gs_onesweep_set_persistent(gs_onesweep* h, int on);
+/* Device probe: do same-address lanes of one LDS atomic get their results in
+ * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
+gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
+/* Tuning aid: global access pattern of a DigitBinningPass without ranking or
+ * look-back (memory floor of the tile shape). */
+gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads,
+                              uint32_t keys_per_thread, void* stream);
 
 /* ---- structural entry points (parity tests, MSD split) --------------------
  * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
