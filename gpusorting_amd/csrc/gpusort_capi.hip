@@ -33,44 +33,21 @@ thread_local int g_last_hip_error = 0;
 // ---- tile-shape table -------------------------------------------------------
 // One launcher per (shape, value bytes, key type).  Shape 0 is the default; the
 // others exist for on-device tuning sweeps (u32 keys only).
-using BinLauncher = void (*)(hipStream_t, uint32_t tiles, const uint32_t*, uint32_t*, const void*, void*,
-                             uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
-                             uint32_t reverse);
+using BinLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, const void*, void*,
+                             uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n,
+                             uint32_t shift, uint32_t reverse);
 
 template <int THREADS, int KPT, int VB, int KT, int RANK>
-void launch_bin(hipStream_t s, uint32_t tiles, const uint32_t* kin, uint32_t* kout, const void* vin, void* vout,
-                uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
+void launch_bin(hipStream_t s, uint32_t grid, const uint32_t* kin, uint32_t* kout, const void* vin, void* vout,
+                uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n, uint32_t shift,
                 uint32_t reverse) {
-    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(tiles + (GS_LB ? gs::NSCAN_WAVES / (THREADS / 64) : 0u)), dim3(THREADS), 0, s, kin,
-                       kout, vin, vout, desc, counter, status, n, shift, reverse);
-}
-
-// persistent, software-pipelined form: grid = resident workgroups (occupancy x CUs), each loops over tickets
-template <int THREADS, int KPT, int VB, int KT, int RANK>
-void launch_bin_persistent(hipStream_t s, uint32_t tiles, const uint32_t* kin, uint32_t* kout, const void* vin,
-                           void* vout, uint32_t* desc, uint32_t* counter, uint32_t* status, uint32_t n, uint32_t shift,
-                           uint32_t reverse) {
-    static int resident = 0;  // per instantiation
-    if (resident == 0) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &per_cu, gs::digit_binning_persistent<THREADS, KPT, VB, KT, RANK>, THREADS, 0) == hipSuccess &&
-            per_cu > 0)
-            resident = per_cu * prop.multiProcessorCount;
-        else
-            resident = 256;
-    }
-    const uint32_t grid = tiles < (uint32_t)resident ? tiles : (uint32_t)resident;
-    hipLaunchKernelGGL((gs::digit_binning_persistent<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, kin,
-                       kout, vin, vout, desc, counter, status, n, shift, reverse);
+    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, kin,
+                       kout, vin, vout, desc, counters, info, status, n, shift, reverse);
 }
 
 struct Shape {
     int threads, kpt;
-    BinLauncher fn[2][3][3];   // one tile per workgroup: [rank mode][vb index 0/4/8][key type]; nullptr = not compiled
-    BinLauncher fnp[2][3][3];  // persistent pipelined form
+    BinLauncher fn[2][3][3];  // [rank mode][vb index 0/4/8][key type]; nullptr = not compiled
 };
 
 #define GS_ROWS(T, K, R)                                                                             \
@@ -84,25 +61,13 @@ struct Shape {
         {launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin<T, K, 4, 0, R>, nullptr, nullptr}, \
             {launch_bin<T, K, 8, 0, R>, nullptr, nullptr},                                           \
     }
-#define GS_PROWS(T, K, R)                                                                            \
-    {                                                                                                \
-        {launch_bin_persistent<T, K, 0, 0, R>, launch_bin_persistent<T, K, 0, 1, R>, launch_bin_persistent<T, K, 0, 2, R>}, \
-            {launch_bin_persistent<T, K, 4, 0, R>, launch_bin_persistent<T, K, 4, 1, R>, launch_bin_persistent<T, K, 4, 2, R>}, \
-            {launch_bin_persistent<T, K, 8, 0, R>, launch_bin_persistent<T, K, 8, 1, R>, launch_bin_persistent<T, K, 8, 2, R>}, \
-    }
-#define GS_PROWS_U32(T, K, R)                                                                        \
-    {                                                                                                \
-        {launch_bin_persistent<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin_persistent<T, K, 4, 0, R>, nullptr, nullptr}, \
-            {launch_bin_persistent<T, K, 8, 0, R>, nullptr, nullptr},                                \
-    }
-#define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}, {GS_PROWS(T, K, 0), GS_PROWS(T, K, 1)}}
-#define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}, {GS_PROWS_U32(T, K, 0), GS_PROWS_U32(T, K, 1)}}
+#define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}}
+#define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}}
 
 const Shape g_shapes[] = {
-    GS_FULL(512, 16),  // default
+    GS_FULL(512, 32),  // default: 16384-key tiles, 2 workgroups per CU
 #ifndef GS_NO_TUNING_SHAPES
-    GS_U32ONLY(256, 16), GS_U32ONLY(512, 8),   GS_U32ONLY(1024, 8),
-    GS_U32ONLY(256, 32), GS_U32ONLY(512, 32),  GS_U32ONLY(1024, 16),
+    GS_U32ONLY(512, 16), GS_U32ONLY(256, 32), GS_U32ONLY(1024, 16), GS_U32ONLY(256, 16),
 #endif
 };
 constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
@@ -110,14 +75,13 @@ constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
 inline int vb_index(uint32_t vb) { return vb == 0 ? 0 : vb == 4 ? 1 : 2; }
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// ---- state slab layout (uint32 words) ----------------------------------------
-//  [0..3]   tile ticket counters, one per pass      (reference m_index)
-//  [4]      device status word
-//  [16..1039] global histogram, 4 x 256            (reference m_globalHistogram)
-//  [1040..] descriptors: pass p at 1040 + p*(tiles+1)*256, (tiles+1) rows of 256
-constexpr uint32_t SLAB_COUNTERS = 0, SLAB_STATUS = 4, SLAB_GHIST = 16, SLAB_DESC = 16 + 1024;
+using gs::SLAB_COUNTERS;
+using gs::SLAB_DESC;
+using gs::SLAB_HIST;
+using gs::SLAB_INFO;
+using gs::SLAB_STATUS;
 
-constexpr uint32_t MIN_TILE = 2048;  // smallest tile of any compiled shape (sizing of the slab)
+constexpr uint32_t MIN_TILE = 4096;  // smallest tile of any compiled shape (sizing of the slab)
 
 }  // namespace
 
@@ -126,7 +90,6 @@ struct gs_onesweep {
     gs_mode mode;
     uint32_t value_bytes;
     int shape;
-    int persistent; // 1 = persistent software-pipelined DigitBinningPass (default), 0 = one tile per workgroup
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -134,7 +97,6 @@ struct gs_onesweep {
     hipEvent_t ev[GS_PROFILE_SLOTS + 1];
     bool ev_valid;
     bool profile_pending;
-    void* trace_buf;   // experiment builds only (GS_EXP & 2)
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
 };
 
@@ -142,46 +104,51 @@ namespace {
 
 size_t slab_words_for(uint32_t max_keys) {
     const size_t max_tiles = div_up(max_keys, MIN_TILE);
-    return SLAB_DESC + 4 * 2 * (max_tiles + 1) * (size_t)gs::RADIX;
+    return SLAB_DESC + 4 * (max_tiles + 2 * gs::NCH + 1) * (size_t)gs::RADIX;
 }
 
-using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t);
 template <int KT>
-void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* ghist, uint32_t n) {
-    hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, ghist, n);
+void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* hist, uint32_t n, uint32_t seg_len0,
+                 uint32_t p0, uint32_t np) {
+    hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, hist, n,
+                       seg_len0, p0, np);
 }
 const HistLauncher g_hist[3] = {launch_hist<0>, launch_hist<1>, launch_hist<2>};
 
 uint32_t hist_blocks(uint32_t n) {
-    // 16 keys per thread-iteration block sweep; cap at 8 blocks per CU, grid-stride beyond
-    const uint32_t want = div_up(n, gs::GHIST_THREADS * 4 * 4);
-    const uint32_t cap = 256 * 8;
+    const uint32_t want = div_up(n, gs::HIST_CHUNK);
+    const uint32_t cap = 256 * 2;  // 64 KiB of LDS per workgroup: two per CU
     return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
-// Clears the scan state and runs GlobalHistogram + Scan.  Returns tiles.
-gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t* tiles_out,
-                   uint32_t* desc_stride_out) {
+// Clears the scan state and runs GlobalHistogram + Scan for passes p0 .. p0+np-1
+// (pass p0 over position segments, later passes over digit groups of the previous digit).
+struct PassPlan {
+    uint32_t grid, desc_stride;
+};
+gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
+                   uint32_t np, PassPlan* plan) {
     const Shape& sh = g_shapes[h->shape];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
-    const uint32_t desc_stride = 2 * (tiles + 1) * gs::RADIX;  // two slice-major arrays of tiles+1 rows
-    const size_t used_words = SLAB_DESC + 4 * (size_t)desc_stride;
+    const uint32_t rows = tiles + 2 * gs::NCH + 1;  // every chain: its tiles (+1 partial) + row 0
+    const uint32_t desc_stride = rows * gs::RADIX;
+    const size_t used_words = SLAB_DESC + (size_t)np * desc_stride;
+    // position segments of the first pass: equal, multiples of the histogram chunk
+    const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     GS_HIP(hipMemsetAsync(h->slab, 0, used_words * sizeof(uint32_t), s));
-#if (GS_EXP & 2)
-    GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 4, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
-#endif
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
-    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_GHIST, n);
+    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_HIST, n, seg_len0, p0, np);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL(gs::scan_kernel, dim3(4), dim3(256), 0, s, h->slab + SLAB_GHIST, h->slab + SLAB_DESC, desc_stride,
-                       (uint32_t)((GS_LB && !h->persistent) ? 1u : 0u));
+    hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
+                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
-    *tiles_out = tiles;
-    *desc_stride_out = desc_stride;
+    plan->grid = tiles + gs::NCH;  // chains end in partial tiles: at most NCH more tiles than n/tile
+    plan->desc_stride = desc_stride;
     return GS_OK;
 }
 
@@ -195,17 +162,18 @@ gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n,
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
     const Shape& sh = g_shapes[h->shape];
-    BinLauncher fn = (h->persistent ? sh.fnp : sh.fn)[h->rank_mode][vb_index(vb)][kt];
+    BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
-    uint32_t tiles = 0, desc_stride = 0;
-    gs_status st = prologue(h, d_keys, n, kt, s, &tiles, &desc_stride);
+    PassPlan plan;
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan);
     if (st != GS_OK) return st;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     for (uint32_t p = 0; p < 4; ++p) {
         const uint32_t reverse = (order == GS_ORDER_DESCENDING && p == 3) ? 1u : 0u;
-        fn(s, tiles, k[p & 1], k[(p + 1) & 1], v[p & 1], v[(p + 1) & 1], h->slab + SLAB_DESC + (size_t)p * desc_stride,
-           h->slab + SLAB_COUNTERS + p, h->slab + SLAB_STATUS, n, p * 8, reverse);
+        fn(s, plan.grid, k[p & 1], k[(p + 1) & 1], v[p & 1], v[(p + 1) & 1],
+           h->slab + SLAB_DESC + (size_t)p * plan.desc_stride, h->slab + SLAB_COUNTERS + p * 32 * gs::COUNTER_STRIDE,
+           h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + SLAB_STATUS, n, p * 8, reverse);
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
     }
     GS_HIP(hipGetLastError());
@@ -276,14 +244,11 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->value_bytes = value_bytes;
     h->shape = 0;
     h->rank_mode = 0;
-    h->persistent = 1;
-    if (const char* env = getenv("GPUSORT_PERSISTENT")) h->persistent = atoi(env) ? 1 : 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
     h->slab = nullptr;
     h->pinned = nullptr;
-    h->trace_buf = nullptr;
     h->slab_words = slab_words_for(max_keys);
     // Tile ranking: the returning-LDS-atomic path needs same-address lanes of one
     // wave-instruction served in ascending lane order.  Probe the device once per
@@ -297,7 +262,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
                 if (g_shapes[i].threads == t && g_shapes[i].kpt == k) h->shape = i;
     }
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (1024 + 8) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         if (h->slab) (void)hipFree(h->slab);
@@ -326,18 +291,6 @@ gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_
             return GS_OK;
         }
     return GS_ERR_ARG;
-}
-
-gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment builds: 4 * tiles * 8 words
-    if (!h) return GS_ERR_ARG;
-    h->trace_buf = d_buf;
-    return GS_OK;
-}
-
-gs_status gs_onesweep_set_persistent(gs_onesweep* h, int on) {
-    if (!h) return GS_ERR_ARG;
-    h->persistent = on ? 1 : 0;
-    return GS_OK;
 }
 
 gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode) {
@@ -413,12 +366,18 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
     if (!h || !d_keys || !h_hist || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
     if (n == 0 || n > h->max_keys) return GS_ERR_SIZE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    uint32_t tiles, stride;
-    gs_status st = prologue(h, d_keys, n, kt, s, &tiles, &stride);
+    PassPlan plan;
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan);
     if (st != GS_OK) return st;
-    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_GHIST, 1024 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const size_t words = 4 * (size_t)gs::NCH * gs::RADIX;
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipStreamSynchronize(s));
-    memcpy(h_hist, h->pinned, 1024 * sizeof(uint32_t));
+    for (uint32_t q = 0; q < 4; ++q)  // digit totals = joint histogram summed over chains
+        for (uint32_t d = 0; d < gs::RADIX; ++d) {
+            uint32_t g = 0;
+            for (uint32_t x = 0; x < gs::NCH; ++x) g += h->pinned[(q * gs::NCH + x) * gs::RADIX + d];
+            h_hist[q * gs::RADIX + d] = g;
+        }
     return GS_OK;
 }
 
@@ -435,14 +394,14 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
         vb = h->value_bytes;
     }
     const Shape& sh = g_shapes[h->shape];
-    BinLauncher fn = (h->persistent ? sh.fnp : sh.fn)[h->rank_mode][vb_index(vb)][kt];
+    BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    uint32_t tiles, stride;
-    st = prologue(h, d_keys_in, n, kt, s, &tiles, &stride);
+    PassPlan plan;
+    st = prologue(h, d_keys_in, n, kt, s, pass, 1, &plan);  // a stand-alone pass: position segments on ANY input
     if (st != GS_OK) return st;
-    fn(s, tiles, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
-       h->slab + SLAB_DESC + (size_t)pass * stride, h->slab + SLAB_COUNTERS + pass, h->slab + SLAB_STATUS, n, pass * 8,
+    fn(s, plan.grid, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, pass * 8,
        reverse_index ? 1u : 0u);
     GS_HIP(hipGetLastError());
     h->profile_pending = false;

@@ -239,7 +239,7 @@ def test_dispatcher_quick(gpu):
 
 
 def test_every_compiled_shape(gpu, oracle):
-    for t, k in ((512, 16), (256, 16), (512, 8), (1024, 8), (256, 32), (512, 32), (1024, 16)):
+    for t, k in ((512, 32), (512, 16), (256, 32), (1024, 16), (256, 16)):
         s = gpu.OneSweep(1 << 20)
         try:
             s.set_shape(t, k)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """On-device tuning sweep: every compiled tile shape x rank mode x {keys, pairs4, pairs8} at 2^LOG keys.
 Prints one line per configuration with GKeys/s and the per-kernel HIP-event breakdown.
-Usage: python tools/sweep.py [log2_keys=28] [reps=5] [modes=0,4,8] [ranks=0,1] [entropy=0] [persistent=1]"""
+Usage: python tools/sweep.py [log2_keys=28] [reps=5] [modes=0,4,8] [ranks=0,1] [entropy=0]"""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpusorting_amd as g  # noqa: E402
 from gpusorting_amd import _lib  # noqa: E402
 
-SHAPES = [(512, 16), (256, 16), (512, 8), (1024, 8), (256, 32), (512, 32), (1024, 16)]
+SHAPES = [(512, 32), (512, 16), (256, 32), (1024, 16), (256, 16)]
 
 
 def timed(fn, reps=10):
@@ -35,7 +35,7 @@ def main():
     modes = [int(x) for x in (a[2] if len(a) > 2 else "0,4,8").split(",")]
     ranks = [int(x) for x in (a[3] if len(a) > 3 else "0,1").split(",")]
     entropy = int(a[4]) if len(a) > 4 else 0
-    persists = [int(x) for x in (a[5] if len(a) > 5 else "1").split(",")]
+
     n = 1 << log2
     lib = _lib.load()
     keys = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -57,12 +57,11 @@ def main():
         vals = torch.empty(n, dtype=vdt, device="cuda") if vb else None
         valt = torch.empty_like(vals) if vb else None
         for (t, k) in SHAPES:
-            for rank, pers in [(r_, p_) for r_ in ranks for p_ in persists]:
+            for rank in ranks:
                 s = g.OneSweep(n, mode=g.MODE_PAIRS if vb else g.MODE_KEYS_ONLY, value_bytes=vb)
                 try:
                     s.set_shape(t, k)
                     s.set_rank_mode(rank)
-                    s.set_persistent(bool(pers))
                 except g.GpuSortError:
                     s.close()
                     continue
@@ -86,7 +85,7 @@ def main():
                 bpk = 4 + 4 * (8 + 2 * vb)
                 tot = acc["total"]
                 passes = " ".join(f"{acc[f'pass{i}']:.3f}" for i in range(4))
-                print(f"vb={vb} {t:4d}x{k:<2d} rank={rank} pers={pers} tile={t*k:5d}  {n/tot/1e6:7.2f} GKeys/s  total={tot:.3f} ms  "
+                print(f"vb={vb} {t:4d}x{k:<2d} rank={rank} tile={t*k:5d}  {n/tot/1e6:7.2f} GKeys/s  total={tot:.3f} ms  "
                       f"({bpk*n/tot/1e6/8000*100:4.1f}% of 8TB/s)  clear={acc['clear']:.3f} hist={acc['global_histogram']:.3f} "
                       f"scan={acc['scan']:.3f} passes=[{passes}]  sorted={ok}", flush=True)
                 s.close()
