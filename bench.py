@@ -75,6 +75,17 @@ def cpu_baseline(log2n: int):
     }
 
 
+def pmc_traffic(args, sorter):
+    """HBM bytes per DigitBinningPass launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
+    separate rocprofv3 --pmc passes of this same command and committed under profiles/); None if the committed
+    measurement is for another workload/tile shape."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.pairs or args.log2_keys != 28 or args.entropy or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d["traffic_bytes_per_launch"] if f"<{sorter.partition_size // 32},32,0,0," in d["kernel"] else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,7 +235,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "digit_binning_kernel (one 8-bit DigitBinningPass)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(args, sorter),
             "algorithmic_bytes_per_launch": bytes_per_key_pass * n, "avg_launch_ms": pass_ms,
             "frac_of_measured_copy_6290": achieved / 6290.0,
             "whole_sort": {

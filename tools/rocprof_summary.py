@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2) rocpd SQLite output into the text kept under profiles/.
+Usage: rocprof_summary.py <results.db> [more.db ...]   (kernel stats; PMC counters if present)"""
+import sqlite3
+import sys
+
+
+def main():
+    for path in sys.argv[1:]:
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        print(f"== {path}")
+        print("-- kernel stats (top_kernels): name | calls | total_ms | avg_us | %")
+        for name, calls, total, avg, pct in cur.execute(
+                "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
+            print(f"{name[:110]:110s} | {calls:5d} | {total/1e6:10.3f} | {avg/1e3:10.2f} | {pct:6.2f}")
+        try:
+            cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+            rows = list(cur.execute("select * from counters_collection"))
+        except Exception:
+            rows = []
+        if rows:
+            ik = cols.index("kernel_name") if "kernel_name" in cols else cols.index("name")
+            ic = cols.index("counter_name")
+            iv = cols.index("value") if "value" in cols else cols.index("counter_value")
+            agg = {}
+            for r in rows:
+                key = (r[ik][:110], r[ic])
+                a = agg.setdefault(key, [0, 0.0])
+                a[0] += 1
+                a[1] += float(r[iv])
+            print("-- PMC counters: kernel | counter | dispatches | mean value per dispatch")
+            for (k, c), (cnt, tot) in sorted(agg.items()):
+                print(f"{k:110s} | {c} | {cnt} | {tot/cnt:.1f}")
+
+
+if __name__ == "__main__":
+    main()
