@@ -253,3 +253,54 @@ def test_every_compiled_shape(gpu, oracle):
             s.check()
             np.testing.assert_array_equal(to_host(dk, np.uint32), np.sort(keys), err_msg=f"{t}x{k} n={n}")
         s.close()
+
+
+def test_lds_atomic_order_probe(gpu):
+    """The returning-LDS-atomic ranking is only selected when this device probe finds no out-of-order lane."""
+    import ctypes as C
+    import torch
+    from gpusorting_amd import _lib
+    fails = C.c_uint64(123)
+    st = _lib.load().gs_selftest_lds_atomic_order(200, 7, C.byref(fails), int(torch.cuda.current_stream().cuda_stream))
+    assert st == 0 and fails.value == 0
+
+
+@pytest.mark.parametrize("rank_mode", [0, 1])
+@pytest.mark.parametrize("vb", [0, 4])
+def test_both_ranking_paths(gpu, oracle, P, rank_mode, vb):
+    """RANK 0 (64-lane ballot multi-split, the guaranteed path) and RANK 1 (LDS atomic) give identical results."""
+    for n, andc in ((777, 0), (P + 5, 2), (3 * P + 1, 0), ((1 << 20) + 9, 4)):
+        keys = oracle.init_random(n, 3 * n + 1, andc)
+        vals = None if not vb else np.arange(n, dtype=np.uint32)
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        s.set_rank_mode(rank_mode)
+        dk = to_dev(keys)
+        dv = None if not vb else to_dev(vals)
+        s.sort(dk, dv)
+        s.check()
+        ref = oracle.std_sort(keys, vals=vals)
+        rk, rv = (ref, None) if not vb else ref
+        np.testing.assert_array_equal(to_host(dk, np.uint32), rk, err_msg=f"n={n} rank={rank_mode}")
+        if vb:
+            np.testing.assert_array_equal(to_host(dv, np.uint32), rv)
+        s.close()
+
+
+def test_chain_boundaries_and_skewed_chains(gpu, oracle, P):
+    """Multi-chain specifics: digit groups of very different sizes, empty chains, chains that start mid-line."""
+    rng = np.random.default_rng(5)
+    n = 5 * P + 37
+    cases = [
+        (rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32) & np.uint32(0x0F0F0F0F)),   # 16 digit values per byte
+        (rng.integers(0, 3, n).astype(np.uint32) * np.uint32(0x01010101)),                            # 3 values, 13 empty chains
+        np.where(rng.random(n) < 0.9, np.uint32(0x10101010), rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)),
+        (np.arange(n, dtype=np.uint32) * np.uint32(2654435761)),
+    ]
+    for keys in cases:
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        for order in (0, 1):
+            ok, ov = _gpu_sort(gpu, keys, 0, order, vals)
+            rk, rv = oracle.std_sort(keys, 0, order, vals)
+            np.testing.assert_array_equal(ok, rk)
+            np.testing.assert_array_equal(ov, rv)
