@@ -375,7 +375,7 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
     for (uint32_t q = 0; q < 4; ++q)  // digit totals = joint histogram summed over chains
         for (uint32_t d = 0; d < gs::RADIX; ++d) {
             uint32_t g = 0;
-            for (uint32_t x = 0; x < gs::NCH; ++x) g += h->pinned[(q * gs::NCH + x) * gs::RADIX + d];
+            for (uint32_t x = 0; x < gs::NCH; ++x) g += h->pinned[gs::hist_index(q, d, x)];
             h_hist[q * gs::RADIX + d] = g;
         }
     return GS_OK;

@@ -111,65 +111,104 @@ __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
 
 // ---------------------------------------------------------------------------
 // GlobalHistogram: ONE sweep over the keys, `np` joint histograms
-//   H[q][x][d], q = 0..np-1 (digit byte p0+q), x = chain, d = digit:
-//   q == 0 : x = position segment (key index / seg_len0; seg_len0 % HIST_CHUNK == 0)
-//   q >= 1 : x = group of the PREVIOUS digit  (digit_{q-1} * NCH / 256)
+//   H[q](d, x), q = 0..np-1 (digit byte p0+q), d = digit, x = chain:
+//   q == 0 : x = position segment (key index / seg_len0; seg_len0 % HIST_CHUNK == 0); stored [x][d]
+//            (x is constant per workgroup, so [d][x] would put every add on two LDS banks)
+//   q >= 1 : x = group of the PREVIOUS digit = its top log2(NCH) bits; stored [d][x], which makes the
+//            bin ONE bit-field of the key: the 8 + log2(NCH) contiguous bits ending at the top of byte p0+q.
 // 16-byte loads; one LDS histogram per workgroup (ds_add_u32); one global atomic
 // per non-empty bin per workgroup.  grid-stride over HIST_CHUNK-key chunks.
 // ---------------------------------------------------------------------------
 constexpr int GHIST_THREADS = 512;
+constexpr uint32_t LOG_NCH = NCH == 1 ? 0 : NCH == 2 ? 1 : NCH == 4 ? 2 : NCH == 8 ? 3 : NCH == 16 ? 4 : 5;
+
+// index of joint-histogram bin (pass q, digit d, chain x)
+__host__ __device__ constexpr uint32_t hist_index(uint32_t q, uint32_t d, uint32_t x) {
+    return q == 0 ? x * RADIX + d : (q * RADIX + d) * NCH + x;
+}
 
 template <int KT>
 __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                          uint32_t* hist, uint32_t n,
                                                                          uint32_t seg_len0, uint32_t p0, uint32_t np) {
     __shared__ uint32_t s_h[4 * NCH * RADIX];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t bins = np * NCH * RADIX;
     for (uint32_t i = tid; i < bins; i += GHIST_THREADS) s_h[i] = 0;
     __syncthreads();
 
     const uint32_t shift0 = p0 * 8u;
-    auto count_key = [&](uint32_t b, uint32_t x0) {
-        uint32_t x = x0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            if (q < np) {
-                const uint32_t d = (b >> (shift0 + 8u * q)) & 255u;
-                atomicAdd(&s_h[(q * NCH + x) * RADIX + d], 1u);
-                x = (d * NCH) >> 8;
-            }
-        }
+    auto bin_of = [&](uint32_t b, uint32_t q, uint32_t x0) -> uint32_t {
+        if (q == 0) return hist_index(0, (b >> shift0) & 255u, x0);
+        return q * (RADIX * NCH) + __builtin_amdgcn_ubfe(b, shift0 + 8u * q - LOG_NCH, 8u + LOG_NCH);
     };
 
+    uint32_t skew_mode = 0;  // bit q (wave-uniform): a dominant bin was seen for byte q; cleared when it fades
+    uint32_t sticky[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // wave-uniform guess of that bin
     const uint32_t nchunks = (n + HIST_CHUNK - 1) / HIST_CHUNK;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t base = c * HIST_CHUNK;
         const uint32_t x0 = base / seg_len0;  // uniform: the whole chunk lies in one position segment
         if (base + HIST_CHUNK <= n) {
             const uint4 t = reinterpret_cast<const uint4*>(keys + base)[tid];
-            count_key(to_bits<KT>(t.x), x0);
-            count_key(to_bits<KT>(t.y), x0);
-            count_key(to_bits<KT>(t.z), x0);
-            count_key(to_bits<KT>(t.w), x0);
+            const uint32_t b[4] = {to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)};
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                if (q < np) {
+                    uint32_t bin[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], q, x0);
+                    // Skew (Thearling-Smith presets, constant bytes): same-address LDS atomics serialise
+                    // per lane.  Cheap probe on the first key: do >= 8 lanes share the first lane's bin?
+                    const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin[0]);
+                    const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
+                    if (pc >= 8) {
+                        skew_mode |= 1u << q;
+                        if (pc >= 24 || sticky[q] == 0xffffffffu) sticky[q] = b0;  // (re)learn the dominant bin
+                    }
+                    if (skew_mode & (1u << q)) {
+                        // lanes holding the remembered dominant bin are counted with ONE add of their
+                        // popcount (by their first lane); all other lanes add individually
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(bin[j] == sticky[q]);
+                            hit += (uint32_t)__popcll(m);
+                            if (bin[j] != sticky[q]) atomicAdd(&s_h[bin[j]], 1u);
+                            else if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u)
+                                atomicAdd(&s_h[sticky[q]], (uint32_t)__popcll(m));
+                        }
+                        if (hit < 32) {  // the guess covers < 1/8 of the lanes: relearn, or leave skew mode
+                            sticky[q] = b0;
+                            if (pc < 8) skew_mode &= ~(1u << q);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&s_h[bin[j]], 1u);
+                    }
+                }
+            }
         } else {
-            for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) count_key(to_bits<KT>(keys[i]), x0);
+            for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
+                const uint32_t kb = to_bits<KT>(keys[i]);
+                for (uint32_t q = 0; q < np; ++q) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
+            }
         }
     }
     __syncthreads();
-    for (uint32_t b = tid; b < bins; b += GHIST_THREADS) {
-        const uint32_t s = s_h[b];
-        if (s) atomicAdd(&hist[b], s);
+    for (uint32_t i = tid; i < bins; i += GHIST_THREADS) {
+        const uint32_t v = s_h[i];
+        if (v) atomicAdd(&hist[i], v);
     }
 }
 
 // ---------------------------------------------------------------------------
 // Scan: per pass q (one workgroup each, 256 threads = digits)
-//   G_q[d]      = sum_x H[q][x][d]                 digit totals
+//   G_q[d]      = sum_x H[q][d][x]                 digit totals
 //   dstart[d]   = exclusive prefix of G_q          global start of digit d's run
 //   seg_start[] : q == 0 -> x*seg_len0 ; q >= 1 -> starts of the digit-(q-1) groups
 //   row_base[]  : first descriptor row of chain x  (chain x owns tiles_x + 1 rows)
-//   row 0 of chain x seeded INCLUSIVE with dstart[d] + sum_{x'<x} H[q][x'][d]
+//   row 0 of chain x seeded INCLUSIVE with dstart[d] + sum_{x'<x} H[q][d][x']
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_t* desc, uint32_t* info,
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
@@ -178,7 +217,6 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_rowbase[NCH + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
-    const uint32_t* Hq = hist + (size_t)q * NCH * RADIX;
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
 
@@ -189,9 +227,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
             s_cum[tid] = s < n ? (uint32_t)s : n;
         }
     } else {
-        const uint32_t* Hp = hist + (size_t)(q - 1) * NCH * RADIX;
         uint32_t g = 0;
-        for (uint32_t x = 0; x < NCH; ++x) g += Hp[x * RADIX + tid];
+        for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(q - 1, tid, x)];
         const uint32_t incl = wave_inclusive_scan(g, lane);
         if (lane == 63) s_wtot[wave] = incl;
         __syncthreads();
@@ -223,17 +260,21 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
 
     // digit starts and chain bases
     uint32_t g = 0;
-    for (uint32_t x = 0; x < NCH; ++x) g += Hq[x * RADIX + tid];
+    for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(q, tid, x)];
     __syncthreads();
     const uint32_t incl = wave_inclusive_scan(g, lane);
     if (lane == 63) s_wtot[wave] = incl;
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < wave; ++w) base += s_wtot[w];
+    // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
+    // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
+    const unsigned long long heavy = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
+    if (lane == 0 && heavy) atomicOr(&my_info[2 * (NCH + 1)], 1u);
     uint32_t run = base + incl - g;  // dstart[tid]
     for (uint32_t x = 0; x < NCH; ++x) {
         my_desc[(size_t)s_rowbase[x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
-        run += Hq[x * RADIX + tid];
+        run += hist[hist_index(q, tid, x)];
     }
 }
 
@@ -388,11 +429,45 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         // where the LDS hands same-address lanes of ONE wave-instruction their
         // results in ascending lane order; gs_selftest_lds_atomic_order() probes
         // exactly that on the device before this path is ever selected.
+        if (info[2 * (NCH + 1)] == 0u) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t d = (key[i] >> shift) & 255u;
-            const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            offp[i >> 1] |= r << (16 * (i & 1));
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                offp[i >> 1] |= r << (16 * (i & 1));
+            }
+        } else {
+            // Skewed pass: the lanes holding the wave's remembered dominant digit take ONE add of
+            // their popcount (issued by their first lane) and rank themselves with mbcnt; all other
+            // lanes use the per-lane atomic.  The group contains ALL lanes of that digit, so group and
+            // per-lane adds never meet on one counter inside a round; rounds are ordered by the
+            // in-order LDS queue.  The guess is relearned from the first lane whenever it covers < 8 lanes.
+            uint32_t sticky = 0xffffffffu;  // wave-uniform
+#pragma unroll 4
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                unsigned long long m = __builtin_amdgcn_ballot_w64(d == sticky);
+                if (__popcll(m) < 8) {
+                    sticky = __builtin_amdgcn_readfirstlane(d);
+                    m = __builtin_amdgcn_ballot_w64(d == sticky);
+                }
+                uint32_t r;
+                if (__popcll(m) >= 8) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                    uint32_t base = 0;
+                    if (lane == l)
+                        base = __hip_atomic_fetch_add(&whist[sticky], (uint32_t)__popcll(m), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = __builtin_amdgcn_readlane(base, l);
+                    if (d == sticky)
+                        r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    else
+                        r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (i & 1) offp[i >> 1] |= r << 16; else offp[i >> 1] |= r;
+            }
         }
     }
     __syncthreads();
@@ -473,6 +548,18 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     __syncthreads();
 
+    // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
+    // while the keys are scattered ----
+    V val[VB != 0 ? KPT : 1];
+    if constexpr (VB != 0) {
+        const V* vals_in = reinterpret_cast<const V*>(vals_in_);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            val[i] = (full || (idx >= lo && idx < hi)) ? vals_in[idx] : V(0);
+        }
+    }
+
     // ---- scatter runs to global memory (slot i of the stage -> s_gbase[digit] + i) ----
     uint32_t digs[VB != 0 ? KPT / 4 : 1];  // digit of stage slot tid + j*THREADS, 4 per register (value phase)
     if constexpr (VB != 0) {
@@ -492,16 +579,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
 
     if constexpr (VB != 0) {
-        const V* vals_in = reinterpret_cast<const V*>(vals_in_);
         V* vals_out = reinterpret_cast<V*>(vals_out_);
         V* s_vstage = reinterpret_cast<V*>(s_raw);
         __syncthreads();  // everyone is done reading the key stage
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = my_base + i * 64u;
-            const V val = (full || (idx >= lo && idx < hi)) ? vals_in[idx] : V(0);
-            s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val;
-        }
+        for (int i = 0; i < KPT; ++i) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
