@@ -65,9 +65,10 @@ struct Shape {
 #define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}}
 
 const Shape g_shapes[] = {
-    GS_FULL(512, 32),  // default: 16384-key tiles, 2 workgroups per CU
+    GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
+    GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
 #ifndef GS_NO_TUNING_SHAPES
-    GS_U32ONLY(512, 16), GS_U32ONLY(256, 32), GS_U32ONLY(1024, 16), GS_U32ONLY(256, 16),
+    GS_U32ONLY(512, 16), GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
 #endif
 };
 constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
@@ -97,6 +98,7 @@ struct gs_onesweep {
     hipEvent_t ev[GS_PROFILE_SLOTS + 1];
     bool ev_valid;
     bool profile_pending;
+    void* trace_buf;   // experiment builds only (GS_EXP & 2): per-tile phase timestamps
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
 };
 
@@ -141,6 +143,9 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     GS_HIP(hipMemsetAsync(h->slab, 0, used_words * sizeof(uint32_t), s));
+#if (GS_EXP & 2)
+    GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
+#endif
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_HIST, n, seg_len0, p0, np);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
@@ -220,8 +225,9 @@ int gs_last_hip_error(void) { return g_last_hip_error; }
 
 size_t gs_onesweep_temp_bytes(uint32_t max_keys) { return slab_words_for(max_keys) * sizeof(uint32_t); }
 
-uint32_t gs_onesweep_partition_size(gs_mode, uint32_t) {
-    return (uint32_t)g_shapes[0].threads * g_shapes[0].kpt;
+uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes) {
+    const Shape& sh = g_shapes[(mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0];
+    return (uint32_t)sh.threads * sh.kpt;
 }
 
 gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes) {
@@ -242,13 +248,14 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->max_keys = max_keys;
     h->mode = mode;
     h->value_bytes = value_bytes;
-    h->shape = 0;
+    h->shape = (mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0;
     h->rank_mode = 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
     h->slab = nullptr;
     h->pinned = nullptr;
+    h->trace_buf = nullptr;
     h->slab_words = slab_words_for(max_keys);
     // Tile ranking: the returning-LDS-atomic path needs same-address lanes of one
     // wave-instruction served in ascending lane order.  Probe the device once per
@@ -291,6 +298,12 @@ gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_
             return GS_OK;
         }
     return GS_ERR_ARG;
+}
+
+gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment builds: 4 passes x grid x 8 words
+    if (!h) return GS_ERR_ARG;
+    h->trace_buf = d_buf;
+    return GS_OK;
 }
 
 gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode) {

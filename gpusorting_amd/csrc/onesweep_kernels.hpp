@@ -52,6 +52,13 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #ifndef GS_EXP
 #define GS_EXP 0  // experiment flags (ablation builds only): 1 = no look-back wait
 #endif
+// GS_EXP & 2: per-tile phase timestamps (10 ns ticks, lane 0 of wave 0) into the buffer whose
+// address the host stored in the slab at STATUS+8; 8 words per (pass, block).
+#if (GS_EXP & 2)
+#define GS_TRACE(slot) do { if (tid == 0) trace[(slot)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define GS_TRACE(slot) do { } while (0)
+#endif
 #ifndef GS_LOOKBACK_BATCH
 #define GS_LOOKBACK_BATCH 1  // descriptor rows fetched per look-back round trip (walks are short with 16 chains)
 #endif
@@ -145,12 +152,10 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 
     uint32_t skew_mode = 0;  // bit q (wave-uniform): a dominant bin was seen for byte q; cleared when it fades
     uint32_t sticky[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // wave-uniform guess of that bin
-    const uint32_t nchunks = (n + HIST_CHUNK - 1) / HIST_CHUNK;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t base = c * HIST_CHUNK;
-        const uint32_t x0 = base / seg_len0;  // uniform: the whole chunk lies in one position segment
-        if (base + HIST_CHUNK <= n) {
-            const uint4 t = reinterpret_cast<const uint4*>(keys + base)[tid];
+    // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
+    // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
+    constexpr uint32_t HIST_UNROLL = 4;
+    auto process = [&](const uint4 t, const uint32_t x0) {
             const uint32_t b[4] = {to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)};
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
@@ -188,10 +193,28 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                     }
                 }
             }
-        } else {
-            for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
-                const uint32_t kb = to_bits<KT>(keys[i]);
-                for (uint32_t q = 0; q < np; ++q) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
+    };
+    const uint32_t nchunks = (n + HIST_CHUNK - 1) / HIST_CHUNK;
+    for (uint32_t c0 = blockIdx.x * HIST_UNROLL; c0 < nchunks; c0 += gridDim.x * HIST_UNROLL) {
+        uint4 t[HIST_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
+            const uint32_t base = (c0 + u) * HIST_CHUNK;
+            if (c0 + u < nchunks && base + HIST_CHUNK <= n) t[u] = reinterpret_cast<const uint4*>(keys + base)[tid];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
+            const uint32_t base = (c0 + u) * HIST_CHUNK;
+            if (c0 + u < nchunks) {
+                const uint32_t x0 = base / seg_len0;  // uniform: a whole chunk lies in one position segment
+                if (base + HIST_CHUNK <= n) {
+                    process(t[u], x0);
+                } else {
+                    for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
+                        const uint32_t kb = to_bits<KT>(keys[i]);
+                        for (uint32_t q = 0; q < np; ++q) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
+                    }
+                }
             }
         }
     }
@@ -336,6 +359,12 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+#if (GS_EXP & 2)
+    uint32_t* trace = reinterpret_cast<uint32_t*>(((unsigned long long)status[9] << 32) | status[8]) +
+                      ((size_t)(shift >> 3) * gridDim.x + blockIdx.x) * 8;
+    uint32_t trace_trips = 0;
+#endif
+    GS_TRACE(0);
     // ---- claim a tile.  Fast path: ONE returning atomic on the ticket counter of
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
     // a chain is the start order, so every predecessor of a claimed tile is running.
@@ -375,6 +404,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t head = lo - tile_base;  // masked keys in front (first tile of a chain only)
     const bool full = (count == TILE);
     uint32_t* cdesc = desc + (size_t)info[NCH + 1 + chain] * RADIX;  // row 0 of this chain
+    GS_TRACE(1);
 
     // ---- load (wave-striped, coalesced 256 B per wave-instruction) ----
     uint32_t key[KPT];
@@ -470,6 +500,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             }
         }
     }
+    GS_TRACE(2);
     __syncthreads();
 
     // ---- per-digit: exclusive prefix over waves, tile total, publish, digit scan ----
@@ -498,6 +529,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     __syncthreads();
 
+    GS_TRACE(3);
     // ---- stage keys in LDS, sorted by digit (stable) ----
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -518,7 +550,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         int32_t k = (int32_t)tile;
         uint32_t spins = 0;
         bool done = (GS_EXP & 1) != 0;
+        GS_TRACE(4);
         while (!done) {
+#if (GS_EXP & 2)
+            ++trace_trips;
+#endif
             uint32_t v[GS_LOOKBACK_BATCH];
 #pragma unroll
             for (int j = 0; j < GS_LOOKBACK_BATCH; ++j) {
@@ -545,6 +581,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
         st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], ((prev + tile_total) << 2) | FLAG_INCLUSIVE);
         s_gbase[tid] = prev - dpre - (tid == 0 ? head : 0u);  // digit 0's real keys start `head` slots into its run
+        GS_TRACE(5);
+#if (GS_EXP & 2)
+        if (tid == 0) trace[7] = trace_trips | (chain << 16) | (1u << 31);
+#endif
     }
     __syncthreads();
 
@@ -577,6 +617,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         if (full || (i >= head && i < head + count)) keys_out[o] = from_bits<KT>(kb);
         if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
     }
+    GS_TRACE(6);
 
     if constexpr (VB != 0) {
         V* vals_out = reinterpret_cast<V*>(vals_out_);

@@ -66,13 +66,14 @@ class HipLocalEngine:
 
 class ShardedOneSweep:
     def __init__(self, shard_keys: int, engine=None, group=None, slack: float = 1.25, pairs: bool = False,
-                 value_bytes: int = 4):
+                 value_bytes: int = 4, always_exchange: bool = False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.shard_keys = int(shard_keys)
         self.capacity = min(int(shard_keys * slack) + 256, _lib.GS_MAX_KEYS)
         self.pairs = pairs
+        self.always_exchange = always_exchange  # run the split/exchange path even for one rank (single-GPU tests)
         self.engine = engine if engine is not None else HipLocalEngine(self.capacity, pairs, value_bytes)
         dev = self.engine.device
         self._part = self.engine.empty_like_keys(self.shard_keys)
@@ -93,7 +94,7 @@ class ShardedOneSweep:
         """
         n = keys.numel() if n is None else int(n)
         eng, W = self.engine, self.world
-        if W == 1:
+        if W == 1 and not self.always_exchange:
             self._recv[:n].copy_(keys[:n])
             if values is not None:
                 self._recv_v[:n].copy_(values[:n])

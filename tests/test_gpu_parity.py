@@ -304,3 +304,34 @@ def test_chain_boundaries_and_skewed_chains(gpu, oracle, P):
             rk, rv = oracle.std_sort(keys, 0, order, vals)
             np.testing.assert_array_equal(ok, rk)
             np.testing.assert_array_equal(ov, rv)
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_sharded_path_single_rank_nccl(gpu, oracle, pairs):
+    """The multi-GPU pipeline (top-byte histogram -> all_gather -> splitters -> stable MSD partition ->
+    all_to_all_single -> local sort) on ONE rank over RCCL, forced through the exchange path."""
+    import torch
+    import torch.distributed as dist
+    from gpusorting_amd.sharded import ShardedOneSweep
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n = (1 << 20) + 77
+        keys = oracle.init_random(n, 99, 1)
+        vals = np.arange(n, dtype=np.uint32) if pairs else None
+        s = ShardedOneSweep(n, pairs=pairs, value_bytes=4, always_exchange=True)
+        bk, bv, nb = s.sort(to_dev(keys), values=None if not pairs else to_dev(vals))
+        s.engine.sorter.check()
+        assert nb == n
+        ref = oracle.std_sort(keys, vals=vals)
+        rk, rv = (ref, None) if not pairs else ref
+        np.testing.assert_array_equal(to_host(bk, np.uint32), rk)
+        if pairs:
+            np.testing.assert_array_equal(to_host(bv, np.uint32), rv)
+    finally:
+        if created:
+            dist.destroy_process_group()
