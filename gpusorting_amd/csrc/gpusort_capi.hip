@@ -61,6 +61,8 @@ struct Shape {
         {launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin<T, K, 4, 0, R>, nullptr, nullptr}, \
             {launch_bin<T, K, 8, 0, R>, nullptr, nullptr},                                           \
     }
+#define GS_ROWS_KEYS(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}
+#define GS_KEYSONLY(T, K) {T, K, {GS_ROWS_KEYS(T, K, 0), GS_ROWS_KEYS(T, K, 1)}}
 #define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}}
 #define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}}
 

@@ -100,6 +100,25 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// streaming accesses of the key/value arrays (every element is touched once per pass)
+#ifndef GS_NT
+#define GS_NT 1  // bit 0: non-temporal key loads in keys-only sorts (pass 0: -7 %; pairs: +10 %, so not there),
+                 // bit 1: non-temporal stores (-40 %: the scatter needs L2 write-combining) — measured, r01_sweep_v21
+#endif
+template <bool NT, class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if constexpr (NT && (GS_NT & 1)) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#if (GS_NT & 2)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t my_base = tile_base + wave * (64u * KPT) + lane;
     if (full) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(keys_in[my_base + i * 64u]);
+        for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(ld_stream<VB == 0>(keys_in + my_base + i * 64u));
     } else {
         // Masked slots become dummy keys that are never written: in FRONT of the segment
         // all-zero bits (digit 0: being first in array order they open the digit-0 run, stage
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = my_base + i * 64u;
-            key[i] = (idx >= lo && idx < hi) ? to_bits<KT>(keys_in[idx]) : (idx < lo ? 0u : 0xffffffffu);
+            key[i] = (idx >= lo && idx < hi) ? to_bits<KT>(ld_stream<VB == 0>(keys_in + idx)) : (idx < lo ? 0u : 0xffffffffu);
         }
     }
 
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = my_base + i * 64u;
-            val[i] = (full || (idx >= lo && idx < hi)) ? vals_in[idx] : V(0);
+            val[i] = (full || (idx >= lo && idx < hi)) ? ld_stream<false>(vals_in + idx) : V(0);
         }
     }
 
@@ -614,7 +633,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         uint32_t o = s_gbase[d] + i;
         if (reverse) o = n - 1u - o;
         if (GS_EXP & 1) o = (tile_base + i) % n;  // ablation: positions are meaningless without the look-back
-        if (full || (i >= head && i < head + count)) keys_out[o] = from_bits<KT>(kb);
+        if (full || (i >= head && i < head + count)) st_stream(keys_out + o, from_bits<KT>(kb));
         if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
     }
     GS_TRACE(6);
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
             if (reverse) o = n - 1u - o;
             if (GS_EXP & 1) o = (tile_base + i) % n;
-            if (full || (i >= head && i < head + count)) vals_out[o] = s_vstage[i];
+            if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
         }
     }
 }
