@@ -11,10 +11,13 @@ $(LIB): $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
 oracle:
 	$(MAKE) -C oracle
-tools: build/gpusorting_main
+tools: build/gpusorting_main build/rocprim_compare
 build/gpusorting_main: tools/gpusorting_main.cpp include/gpusort/OneSweepDispatcher.hpp $(LIB)
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Iinclude tools/gpusorting_main.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
+build/rocprim_compare: tools/rocprim_compare.cpp $(LIB)
+	@mkdir -p build
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/rocprim_compare.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
 clean:
 	rm -rf build $(LIB); $(MAKE) -C oracle clean
 .PHONY: all oracle tools clean
