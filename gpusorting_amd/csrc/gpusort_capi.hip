@@ -93,6 +93,7 @@ struct gs_onesweep {
     gs_mode mode;
     uint32_t value_bytes;
     int shape;
+    int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -166,8 +167,31 @@ gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n,
     return GS_OK;
 }
 
+// single-tile fast path (n <= gs::SMALL_TILE): one launch, no scan state
+using SmallLauncher = void (*)(hipStream_t, uint32_t*, void*, uint32_t, uint32_t);
+template <int VB, int KT, int RANK>
+void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_t descending) {
+    hipLaunchKernelGGL((gs::small_sort_kernel<VB, KT, RANK>), dim3(1), dim3(gs::SMALL_THREADS), 0, s, keys, vals, n,
+                       descending);
+}
+#define GS_SMALL_ROW(VB, R) {launch_small<VB, 0, R>, launch_small<VB, 1, R>, launch_small<VB, 2, R>}
+const SmallLauncher g_small[2][3][3] = {{GS_SMALL_ROW(0, 0), GS_SMALL_ROW(4, 0), GS_SMALL_ROW(8, 0)},
+                                        {GS_SMALL_ROW(0, 1), GS_SMALL_ROW(4, 1), GS_SMALL_ROW(8, 1)}};
+
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
+    if (n <= gs::SMALL_TILE && h->small_path) {
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
+        g_small[h->rank_mode][vb_index(vb)][kt](s, static_cast<uint32_t*>(d_keys), d_vals, n,
+                                                  order == GS_ORDER_DESCENDING ? 1u : 0u);
+        if (h->profiling)  // everything is charged to slot 0 (and the total)
+            for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
+        GS_HIP(hipGetLastError());
+        h->profile_pending = h->profiling != 0;
+        // the scan state is untouched, so a later gs_onesweep_check() still reads the last tiled sort's word;
+        // the single-tile kernel has no spin and cannot time out
+        return GS_OK;
+    }
     const Shape& sh = g_shapes[h->shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
@@ -252,6 +276,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->value_bytes = value_bytes;
     h->shape = (mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0;
     h->rank_mode = 0;
+    h->small_path = 1;
+    if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
@@ -271,6 +297,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
                 if (g_shapes[i].threads == t && g_shapes[i].kpt == k) h->shape = i;
     }
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
+    // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
+    if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_HIST * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
@@ -305,6 +333,12 @@ gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_
 gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment builds: 4 passes x grid x 8 words
     if (!h) return GS_ERR_ARG;
     h->trace_buf = d_buf;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on) {
+    if (!h) return GS_ERR_ARG;
+    h->small_path = on ? 1 : 0;
     return GS_OK;
 }
 
@@ -419,7 +453,9 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, pass * 8,
        reverse_index ? 1u : 0u);
     GS_HIP(hipGetLastError());
-    h->profile_pending = false;
+    if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
+        for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
+    h->profile_pending = h->profiling != 0;
     return GS_OK;
 }
 

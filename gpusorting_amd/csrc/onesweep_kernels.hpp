@@ -396,18 +396,30 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
     uint32_t seg_start = info[chain], seg_end = info[chain + 1];
     if (tile >= (seg_end - (seg_start & ~63u) + TILE - 1) / TILE) {  // uniform
+        // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
+        // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
         __syncthreads();
-        if (tid == 0) {
-            uint32_t got_x = 0, got_t = 0xffffffffu;
-            for (uint32_t a = 1; a < NCH; ++a) {
-                const uint32_t x = (chain + a) & (NCH - 1);
-                const uint32_t tiles_x = (info[x + 1] - (info[x] & ~63u) + TILE - 1) / TILE;
-                if (info[x + 1] == info[x] || ld_agent(&counters[x * COUNTER_STRIDE]) >= tiles_x) continue;
-                const uint32_t t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
-                if (t < tiles_x) { got_x = x; got_t = t; break; }
+        if (wave == 0) {
+            uint32_t tiles_x = 0;
+            bool open = false;
+            if (lane < NCH) {
+                const uint32_t s0 = info[lane], s1 = info[lane + 1];
+                tiles_x = (s1 - (s0 & ~63u) + TILE - 1) / TILE;
+                open = (s1 != s0) && ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
             }
-            s_misc[0] = got_x;
-            s_misc[1] = got_t;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(open);
+            uint32_t got_x = 0, got_t = 0xffffffffu;
+            while (m) {  // wave-uniform: try the open chains one by one, starting after our own
+                const unsigned long long rot = (m >> chain) | (m << ((NCH - chain) & 63));
+                const uint32_t x = (chain + (uint32_t)__builtin_ctzll(rot & ((1ull << NCH) - 1ull))) & (NCH - 1);
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                const uint32_t tx = __builtin_amdgcn_readlane(tiles_x, x);
+                if (t < tx) { got_x = x; got_t = t; break; }
+                m &= ~(1ull << x);
+            }
+            if (lane == 0) { s_misc[0] = got_x; s_misc[1] = got_t; }
         }
         __syncthreads();
         chain = s_misc[0];
@@ -652,6 +664,119 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if (reverse) o = n - 1u - o;
             if (GS_EXP & 1) o = (tile_base + i) % n;
             if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Single-tile sort (n <= SMALL_TILE): ONE workgroup does all four passes in LDS — one
+// launch instead of clear + histogram + scan + 4 passes (at small n the multi-kernel
+// path is ~105 us of nearly empty launches at idle clocks).  Same tile machinery as
+// the DigitBinningPass: wave-striped order, per-wave ranking, prefix over waves and
+// digits, stage sorted by digit; the staged order is the next pass's array order.
+// Descending = final index reversal (SortCommon.hlsl:594-597).  Slots >= n hold
+// all-one dummy keys that stay behind every real key in every pass.
+// ---------------------------------------------------------------------------
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_KPT = 16;
+constexpr uint32_t SMALL_TILE = SMALL_THREADS * SMALL_KPT;  // 8192
+
+template <int VB, int KT, int RANK>
+__global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* keys, void* vals_, uint32_t n,
+                                                                   uint32_t descending) {
+    using V = typename ValT<VB>::type;
+    constexpr int KPT = SMALL_KPT, WAVES = SMALL_THREADS / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[SMALL_TILE];
+    __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? SMALL_TILE : 1];
+    __shared__ uint32_t s_whist[WAVES * RADIX];
+    __shared__ uint32_t s_wtot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t my_base = wave * (64u * KPT) + lane;
+    uint32_t* whist = s_whist + wave * RADIX;
+
+    uint32_t key[KPT];
+    V val[VB != 0 ? KPT : 1];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = my_base + i * 64u;
+        key[i] = idx < n ? to_bits<KT>(keys[idx]) : 0xffffffffu;
+        if constexpr (VB != 0) val[i] = idx < n ? reinterpret_cast<const V*>(vals_)[idx] : V(0);
+    }
+
+#pragma unroll 1
+    for (uint32_t shift = 0; shift < 32; shift += 8) {
+        for (uint32_t i = tid; i < WAVES * RADIX; i += SMALL_THREADS) s_whist[i] = 0;
+        __syncthreads();
+        uint32_t off[KPT];
+        if constexpr (RANK == 0) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)key[i], shift + k, 1);
+                    const unsigned long long b = __builtin_amdgcn_ballot_w64(B != 0u);
+                    acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (uint32_t)b, B, 0xF6);
+                    acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (uint32_t)(b >> 32), B, 0xF6);
+                }
+                const uint32_t plo = ~acc_lo, phi = ~acc_hi;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                const uint32_t total = __popc(plo) + __popc(phi);
+                const uint32_t pre = whist[d];
+                if (below == total - 1u) whist[d] = pre + total;
+                asm volatile("" ::: "memory");
+                off[i] = pre + below;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                off[i] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        uint32_t run = 0, scan_incl = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = s_whist[w * RADIX + tid];
+                s_whist[w * RADIX + tid] = run;
+                run += c;
+            }
+            scan_incl = wave_inclusive_scan(run, lane);
+            if (lane == 63) s_wtot[wave] = scan_incl;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
+            const uint32_t dpre = wbase + scan_incl - run;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
+            s_stage[lpos] = key[i];
+            if constexpr (VB != 0) s_vstage[lpos] = val[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            key[i] = s_stage[my_base + i * 64u];
+            if constexpr (VB != 0) val[i] = s_vstage[my_base + i * 64u];
+        }
+        // the next pass starts with a barrier (after zeroing whist) before anything writes the stage
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = my_base + i * 64u;
+        if (idx < n) {
+            const uint32_t o = descending ? n - 1u - idx : idx;
+            keys[o] = from_bits<KT>(key[i]);
+            if constexpr (VB != 0) reinterpret_cast<V*>(vals_)[o] = val[i];
         }
     }
 }

@@ -125,6 +125,9 @@ class OneSweep:
     def set_rank_mode(self, mode: int) -> None:
         check(self._lib.gs_onesweep_set_rank_mode(self._h, mode), "gs_onesweep_set_rank_mode")
 
+    def set_small_path(self, on: bool) -> None:
+        check(self._lib.gs_onesweep_set_small_path(self._h, 1 if on else 0), "gs_onesweep_set_small_path")
+
     def _alts(self, n: int, values: torch.Tensor | None):
         if self._alt_keys is None or self._alt_keys.numel() < n:
             self._alt_keys = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)

@@ -111,6 +111,9 @@ uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
  * returning LDS atomic per key, valid only if gs_selftest_lds_atomic_order()
  * reports 0 failures on this device. */
 gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
+/* n <= 8192 is sorted by ONE workgroup in one launch (all four passes in LDS) unless this is
+ * switched off (tests use 0 to push small sizes through the tiled path as well). */
+gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);

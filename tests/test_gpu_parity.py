@@ -335,3 +335,27 @@ def test_sharded_path_single_rank_nccl(gpu, oracle, pairs):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("small_path", [True, False])
+@pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (0, 2, 1), (4, 1, 1), (8, 0, 0), (4, 0, 0)])
+def test_single_tile_path_and_tiled_path_agree(gpu, oracle, small_path, vb, kt, order):
+    """n <= 8192 takes the one-launch single-tile kernel; with it switched off the same sizes go through
+    clear + histogram + scan + 4 passes.  Both must equal the oracle (stability: value = index)."""
+    for n, andc in ((1, 0), (2, 0), (63, 1), (64, 0), (65, 4), (1000, 0), (4097, 2), (8191, 0), (8192, 3), (8193, 0)):
+        keys = oracle.init_random(n, 7 * n + 3, andc)
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
+        s.set_small_path(small_path)
+        for rank in (0, 1):
+            s.set_rank_mode(rank)
+            dk = to_dev(keys)
+            dv = None if not vb else to_dev(vals)
+            s.sort(dk, dv)
+            s.check()
+            ref = oracle.std_sort(keys, kt, order, vals)
+            rk, rv = (ref, None) if not vb else ref
+            np.testing.assert_array_equal(to_host(dk, np.uint32), rk, err_msg=f"n={n} small={small_path} rank={rank}")
+            if vb:
+                np.testing.assert_array_equal(to_host(dv, vals.dtype), rv, err_msg=f"values n={n} small={small_path}")
+        s.close()
