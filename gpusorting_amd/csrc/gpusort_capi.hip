@@ -369,14 +369,22 @@ gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* 
 
 gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads, uint32_t kpt, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t tiles = n / (threads * kpt);
+    const uint32_t tiles = threads ? n / (threads * (kpt ? kpt : 1u)) : 1u;
     if (!tiles) return GS_ERR_SIZE;
     const uint32_t* in = static_cast<const uint32_t*>(d_in);
     uint32_t* out = static_cast<uint32_t*>(d_out);
     if (threads == 512 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<512, 16>), dim3(tiles), dim3(512), 0, s, in, out, n);
     else if (threads == 1024 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<1024, 16>), dim3(tiles), dim3(1024), 0, s, in, out, n);
     else if (threads == 256 && kpt == 32) hipLaunchKernelGGL((gs::copy_floor_kernel<256, 32>), dim3(tiles), dim3(256), 0, s, in, out, n);
-    else return GS_ERR_ARG;
+    else if (threads == 0) {  // calibration copies: kpt = 0/1/2 copy policy, 3 = read-only sweep
+        const uint32_t nvec = n / 4, grid = 256 * 8;
+        const gs::u32x4* vi = static_cast<const gs::u32x4*>(d_in);
+        gs::u32x4* vo = static_cast<gs::u32x4*>(d_out);
+        if (kpt == 0) hipLaunchKernelGGL(gs::copy_x4_kernel<0>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
+        else if (kpt == 1) hipLaunchKernelGGL(gs::copy_x4_kernel<1>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
+        else if (kpt == 2) hipLaunchKernelGGL(gs::copy_x4_kernel<2>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
+        else hipLaunchKernelGGL(gs::read_x4_kernel, dim3(grid), dim3(256), 0, s, vi, out, nvec);
+    } else return GS_ERR_ARG;
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

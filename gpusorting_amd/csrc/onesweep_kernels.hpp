@@ -849,6 +849,28 @@ __global__ __launch_bounds__(THREADS) void copy_floor_kernel(const uint32_t* in,
     for (int j = 0; j < KPT; ++j) out[tile_base + tid + j * THREADS] = s_stage[tid + j * THREADS];
 }
 
+// Plain streaming copies for calibration of the box's achievable HBM rate: 16-byte grid-stride
+// (mode 0: default policy, 1: non-temporal loads, 2: non-temporal loads and stores), and a read-only sweep.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_x4_kernel(const u32x4* in, u32x4* out, uint32_t nvec) {
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nvec; i += stride) {
+        u32x4 v;
+        if constexpr (MODE >= 1) v = __builtin_nontemporal_load(in + i); else v = in[i];
+        if constexpr (MODE >= 2) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void read_x4_kernel(const u32x4* in, uint32_t* sink, uint32_t nvec) {
+    const uint32_t stride = gridDim.x * 256u;
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 v = in[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
+}
+
 // ---------------------------------------------------------------------------
 // Fixtures: InitRandom and Validate.
 // ---------------------------------------------------------------------------
