@@ -52,3 +52,45 @@ def test_2pow28_properties(gpu, pairs):
     s.check()
     assert bool((again == dk).all().item())
     s.close()
+
+
+def test_maximum_size_2pow30_minus_1(gpu):
+    """Largest n the API accepts (30-bit tile-descriptor payload): 4 GiB of keys.  Properties only:
+    the reference's own pass criterion (no inversion) and all four digit histograms preserved."""
+    import torch
+    n = (1 << 30) - 1
+    dk = torch.empty(n + 1, dtype=torch.int32, device="cuda")[:n]
+    gpu.init_random(dk, 30, 0, n=n)
+    s = gpu.OneSweep(n)
+    h_before = s.global_histogram(dk, n)
+    assert int(h_before[0].sum()) == n
+    s.sort(dk, n=n)
+    s.check()
+    assert gpu.validate(dk, n=n) == 0
+    np.testing.assert_array_equal(s.global_histogram(dk, n), h_before)
+    lo = dk[:4].cpu().numpy().view(np.uint32)
+    hi = dk[n - 4:n].cpu().numpy().view(np.uint32)
+    assert lo[0] <= lo[-1] <= hi[0] <= hi[-1]
+    s.close()
+    with pytest.raises(gpu.GpuSortError):
+        gpu.OneSweep(1 << 30)  # one past the limit: GS_ERR_SIZE
+
+
+@pytest.mark.parametrize("kt,order,vb", [(1, 1, 4), (2, 0, 8), (2, 1, 0)])
+def test_2pow24_typed_keys_exact(gpu, oracle, kt, order, vb):
+    """Typed keys / descending / values at a multi-thousand-tile size, exact against the oracle."""
+    import torch
+    n = (1 << 24) + 12345
+    keys = oracle.init_random(n, 24 + kt, 0)
+    vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+    s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
+    dk = torch.from_numpy(keys.view(np.int32)).cuda()
+    dv = None if not vb else torch.from_numpy(vals.view(np.int32 if vb == 4 else np.int64)).cuda()
+    s.sort(dk, dv)
+    s.check()
+    ref = oracle.std_sort(keys, kt, order, vals)
+    rk, rv = (ref, None) if not vb else ref
+    np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), rk)
+    if vb:
+        np.testing.assert_array_equal(dv.cpu().numpy().view(vals.dtype), rv)
+    s.close()
