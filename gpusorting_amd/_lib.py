@@ -38,6 +38,8 @@ _PROTOS = [
     ("gs_debug_copy_floor", _int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
+    ("gs_onesweep_msd_prepare", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
+    ("gs_onesweep_msd_partition", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("gs_onesweep_set_profiling", _int, [_vp, _int]),
     ("gs_onesweep_get_profile", _int, [_vp, C.POINTER(C.c_float)]),
     ("gs_init_random", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),

@@ -102,6 +102,9 @@ struct gs_onesweep {
     bool ev_valid;
     bool profile_pending;
     void* trace_buf;   // experiment builds only (GS_EXP & 2): per-tile phase timestamps
+    const void* msd_keys;  // shard whose top-byte histogram + scan currently sit in the slab (msd_prepare)
+    uint32_t msd_n, msd_grid;
+    gs_key_type msd_kt;
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
 };
 
@@ -136,6 +139,7 @@ struct PassPlan {
 };
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
                    uint32_t np, PassPlan* plan) {
+    h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     const Shape& sh = g_shapes[h->shape];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
@@ -284,6 +288,9 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->slab = nullptr;
     h->pinned = nullptr;
     h->trace_buf = nullptr;
+    h->msd_keys = nullptr;
+    h->msd_n = h->msd_grid = 0;
+    h->msd_kt = GS_KEY_UINT32;
     h->slab_words = slab_words_for(max_keys);
     // Tile ranking: the returning-LDS-atomic path needs same-address lanes of one
     // wave-instruction served in ascending lane order.  Probe the device once per
@@ -464,6 +471,52 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
     if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
         for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
     h->profile_pending = h->profiling != 0;
+    return GS_OK;
+}
+
+// ---- multi-GPU MSD split in two steps that share ONE histogram + scan of the shard -------------
+gs_status gs_onesweep_msd_prepare(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, uint32_t* h_hist256,
+                                  void* stream) {
+    if (!h || !d_keys || !h_hist256 || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n == 0 || n > h->max_keys || n > GS_MAX_KEYS) return GS_ERR_SIZE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PassPlan plan;
+    gs_status st = prologue(h, d_keys, n, kt, s, 3, 1, &plan);  // top byte, position chains
+    if (st != GS_OK) return st;
+    const size_t words = (size_t)gs::NCH * gs::RADIX;
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    for (uint32_t d = 0; d < gs::RADIX; ++d) {
+        uint32_t g = 0;
+        for (uint32_t x = 0; x < gs::NCH; ++x) g += h->pinned[gs::hist_index(0, d, x)];
+        h_hist256[d] = g;
+    }
+    h->msd_keys = d_keys;
+    h->msd_n = n;
+    h->msd_kt = kt;
+    h->msd_grid = plan.grid;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void* d_keys_out, const void* d_vals_in,
+                                    void* d_vals_out, uint32_t n, void* stream) {
+    if (!h || h->msd_keys == nullptr || h->msd_keys != d_keys_in || h->msd_n != n) return GS_ERR_ARG;  // needs its prepare
+    gs_status st = check_common(h, d_keys_in, d_keys_out, n, h->msd_kt, GS_ORDER_ASCENDING);
+    if (st != GS_OK) return st;
+    uint32_t vb = 0;
+    if (d_vals_in || d_vals_out) {
+        if (h->mode != GS_MODE_PAIRS) return GS_ERR_MODE;
+        if (!d_vals_in || !d_vals_out || misaligned(d_vals_in) || misaligned(d_vals_out)) return GS_ERR_ARG;
+        vb = h->value_bytes;
+    }
+    BinLauncher fn = g_shapes[h->shape].fn[h->rank_mode][vb_index(vb)][h->msd_kt];
+    if (!fn) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    fn(s, h->msd_grid, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, 24, 0u);
+    GS_HIP(hipGetLastError());
+    h->msd_keys = nullptr;  // the scan state is consumed
+    h->profile_pending = false;
     return GS_OK;
 }
 

@@ -189,6 +189,22 @@ class OneSweep:
             None if values_out is None else values_out.data_ptr(), n, pass_index, self.key_type,
             1 if reverse_index else 0, _stream_ptr()), "gs_onesweep_digit_pass")
 
+    def msd_prepare(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
+        """Top-byte histogram of ``keys[:n]`` (256 counts); leaves histogram + scan in the handle for msd_partition."""
+        n = keys.numel() if n is None else int(n)
+        out = (C.c_uint32 * 256)()
+        check(self._lib.gs_onesweep_msd_prepare(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
+              "gs_onesweep_msd_prepare")
+        return np.frombuffer(out, dtype=np.uint32).copy()
+
+    def msd_partition(self, keys_in: torch.Tensor, keys_out: torch.Tensor, n: int | None = None,
+                      values_in: torch.Tensor | None = None, values_out: torch.Tensor | None = None) -> None:
+        n = keys_in.numel() if n is None else int(n)
+        check(self._lib.gs_onesweep_msd_partition(
+            self._h, keys_in.data_ptr(), keys_out.data_ptr(),
+            None if values_in is None else values_in.data_ptr(),
+            None if values_out is None else values_out.data_ptr(), n, _stream_ptr()), "gs_onesweep_msd_partition")
+
     # -- profiling ------------------------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:
         check(self._lib.gs_onesweep_set_profiling(self._h, 1 if enabled else 0), "gs_onesweep_set_profiling")

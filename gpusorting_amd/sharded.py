@@ -52,10 +52,16 @@ class HipLocalEngine:
         return torch.empty(n, dtype=torch.int32, device=self.device)
 
     def top_byte_histogram(self, keys, n) -> np.ndarray:
-        return self.sorter.global_histogram(keys, n)[3].astype(np.int64)
+        # one histogram + scan of the shard serves both the split decision and the partition pass
+        self._prepared = (keys.data_ptr(), n)
+        return self.sorter.msd_prepare(keys, n).astype(np.int64)
 
     def partition_by_top_byte(self, keys, out, n, values=None, values_out=None):
-        self.sorter.digit_pass(keys, out, 3, n=n, values_in=values, values_out=values_out)
+        if getattr(self, "_prepared", None) == (keys.data_ptr(), n):
+            self._prepared = None
+            self.sorter.msd_partition(keys, out, n=n, values_in=values, values_out=values_out)
+        else:
+            self.sorter.digit_pass(keys, out, 3, n=n, values_in=values, values_out=values_out)
 
     def sort(self, keys, n, values=None):
         self.sorter.sort(keys, values, n=n)

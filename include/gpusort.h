@@ -138,6 +138,15 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
                                  uint32_t pass, gs_key_type key_type, int reverse_index,
                                  void* stream);
 
+/* The multi-GPU MSD split in two steps that share ONE histogram + scan of the shard (no reference
+ * counterpart).  prepare: top-byte histogram of d_keys[0..n) to h_hist256[256] on the
+ * host (synchronous).  partition: the stable DigitBinningPass on the top byte of the SAME buffer and n;
+ * must be the next call on this handle (GS_ERR_ARG otherwise). */
+gs_status gs_onesweep_msd_prepare(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type key_type,
+                                  uint32_t* h_hist256, void* stream);
+gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void* d_keys_out,
+                                    const void* d_vals_in, void* d_vals_out, uint32_t n, void* stream);
+
 /* ---- profiling hook --------------------------------------------------------
  * Replaces the cudaEvent pair of BatchTiming* (OneSweepDispatcher.cuh:207-229)
  * with per-kernel HIP events recorded on the sort's own stream.
