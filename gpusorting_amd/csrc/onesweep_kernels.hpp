@@ -76,7 +76,13 @@ constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
 constexpr uint32_t INFO_STRIDE = 80;  // >= 2*(NCH+1)
 constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
 constexpr uint32_t SLAB_DESC = SLAB_HIST + 4 * NCH * RADIX;
-constexpr uint32_t HIST_CHUNK = 2048;  // keys per histogram work item; position segments are multiples of it
+#ifndef GS_GHIST_THREADS
+#define GS_GHIST_THREADS 1024
+#endif
+#ifndef GS_HIST_UNROLL
+#define GS_HIST_UNROLL 4
+#endif
+constexpr uint32_t HIST_CHUNK = 4 * GS_GHIST_THREADS;  // keys per histogram work item (4 per thread); position segments are multiples of it
 
 enum : int { KEY_U32 = 0, KEY_I32 = 1, KEY_F32 = 2 };
 
@@ -145,7 +151,7 @@ __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
 // 16-byte loads; one LDS histogram per workgroup (ds_add_u32); one global atomic
 // per non-empty bin per workgroup.  grid-stride over HIST_CHUNK-key chunks.
 // ---------------------------------------------------------------------------
-constexpr int GHIST_THREADS = 512;
+constexpr int GHIST_THREADS = GS_GHIST_THREADS;
 constexpr uint32_t LOG_NCH = NCH == 1 ? 0 : NCH == 2 ? 1 : NCH == 4 ? 2 : NCH == 8 ? 3 : NCH == 16 ? 4 : 5;
 
 // index of joint-histogram bin (pass q, digit d, chain x)
@@ -173,8 +179,12 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     uint32_t sticky[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // wave-uniform guess of that bin
     // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
     // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
-    constexpr uint32_t HIST_UNROLL = 4;
+    constexpr uint32_t HIST_UNROLL = GS_HIST_UNROLL;
     auto process = [&](const uint4 t, const uint32_t x0) {
+            if (GS_EXP & 4) {  // ablation: stream only, count nothing
+                asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+                return;
+            }
             const uint32_t b[4] = {to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)};
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
@@ -215,6 +225,17 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     };
     const uint32_t nchunks = (n + HIST_CHUNK - 1) / HIST_CHUNK;
     for (uint32_t c0 = blockIdx.x * HIST_UNROLL; c0 < nchunks; c0 += gridDim.x * HIST_UNROLL) {
+        if ((unsigned long long)(c0 + HIST_UNROLL) * HIST_CHUNK <= n) {
+            // common case: HIST_UNROLL full chunks — UNCONDITIONAL loads (conditional ones get an
+            // s_waitcnt vmcnt(0) each from the compiler and end up one at a time in flight)
+            uint4 t[HIST_UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < HIST_UNROLL; ++u)
+                t[u] = reinterpret_cast<const uint4*>(keys + (size_t)(c0 + u) * HIST_CHUNK)[tid];
+#pragma unroll
+            for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(t[u], (c0 + u) * HIST_CHUNK / seg_len0);
+            continue;
+        }
         uint4 t[HIST_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
