@@ -62,6 +62,10 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #ifndef GS_LOOKBACK_BATCH
 #define GS_LOOKBACK_BATCH 1  // descriptor rows fetched per look-back round trip (walks are short with 16 chains)
 #endif
+#ifndef GS_EARLY_LOOKBACK
+#define GS_EARLY_LOOKBACK 0  // 1 = issue the first look-back read before the staging phase; measured -4 % (A/B, two
+                             // runs): the early read mostly returns a not-yet-final row and the wait moves in front of staging
+#endif
 
 // ---- state slab layout (uint32 words), shared by host and kernels -------------
 //  COUNTERS  tile tickets, [pass][chain]                       (reference m_index)
@@ -579,6 +583,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
     }
+#if GS_EARLY_LOOKBACK
+    // first look-back read issued NOW: it flies during the barrier and the staging phase
+    uint32_t early = 0;
+    if (tid < RADIX) early = ld_agent(&cdesc[(size_t)tile * RADIX + tid]);
+#endif
     __syncthreads();
 
     GS_TRACE(3);
@@ -602,6 +611,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         int32_t k = (int32_t)tile;
         uint32_t spins = 0;
         bool done = (GS_EXP & 1) != 0;
+#if GS_EARLY_LOOKBACK
+        bool first_trip = true;
+#endif
         GS_TRACE(4);
         while (!done) {
 #if (GS_EXP & 2)
@@ -611,8 +623,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
             for (int j = 0; j < GS_LOOKBACK_BATCH; ++j) {
                 const int32_t r = k - j < 0 ? 0 : k - j;
+#if GS_EARLY_LOOKBACK
+                if (first_trip && j == 0) { v[0] = early; continue; }  // row `tile`, read before the staging phase
+#endif
                 v[j] = ld_agent(&cdesc[(size_t)r * RADIX + tid]);
             }
+#if GS_EARLY_LOOKBACK
+            first_trip = false;
+#endif
             bool stalled = false;
 #pragma unroll
             for (int j = 0; j < GS_LOOKBACK_BATCH; ++j) {
