@@ -5,10 +5,12 @@ LIB := gpusorting_amd/lib/libgpusort.so
 SRC := gpusorting_amd/csrc/gpusort_capi.hip
 HDR := gpusorting_amd/csrc/onesweep_kernels.hpp include/gpusort.h
 
-all: $(LIB) oracle tools
+all: $(LIB) gpusorting_amd/lib/libgpusort_fault.so oracle tools
 $(LIB): $(SRC) $(HDR)
 	@mkdir -p gpusorting_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
+gpusorting_amd/lib/libgpusort_fault.so: $(SRC) $(HDR)
+	$(HIPCC) $(HIPFLAGS) -shared -DGS_EXP=8 -DGS_SPIN_LIMIT=4096 -DGS_NO_TUNING_SHAPES $(SRC) -o $@
 oracle:
 	$(MAKE) -C oracle
 tools: build/gpusorting_main build/rocprim_compare

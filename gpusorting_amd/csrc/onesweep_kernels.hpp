@@ -35,13 +35,21 @@ constexpr uint32_t RADIX = 256;
 constexpr uint32_t FLAG_NOT_READY = 0;  // tile has published nothing yet
 constexpr uint32_t FLAG_REDUCTION = 1;  // count<<2 = this tile's digit count
 constexpr uint32_t FLAG_INCLUSIVE = 2;  // count<<2 = count of this and all earlier tiles of the chain (+ chain base)
+constexpr uint32_t FLAG_POISON = 3;     // the tile gave up its look-back (bounded spin expired): successors give up too
 constexpr uint32_t FLAG_MASK = 3;
 
 constexpr uint32_t STATUS_OK = 0;
 constexpr uint32_t STATUS_TIMEOUT = 4;  // == GS_ERR_TIMEOUT
 
 // Bound for every look-back spin (polls, each >= ~0.5 us with the sleep): ~1 s.
-constexpr uint32_t SPIN_LIMIT = 1u << 21;
+#ifndef GS_SPIN_LIMIT
+#define GS_SPIN_LIMIT (1u << 21)
+#endif
+constexpr uint32_t SPIN_LIMIT = GS_SPIN_LIMIT;
+// GS_EXP & 8 (fault-injection build, cf. the reference's EmulatedDeadlocking.cu:36-37,339-345): tile 5 of
+// chain 3 never publishes its descriptor, as if its workgroup had stalled; every later tile of that chain
+// must run into the bounded spin, the sort must still finish, and gs_onesweep_check must say GS_ERR_TIMEOUT.
+#define GS_FAULT_TILE(chain, tile) (((GS_EXP)&8) && (chain) == 3u && (tile) == 5u)
 
 #ifndef GS_NCHAINS
 #define GS_NCHAINS 16  // independent chained scans per pass (power of two, <= 32)
@@ -414,8 +422,16 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // a chain is the start order, so every predecessor of a claimed tile is running.
     // Only when that chain is already fully claimed does thread 0 try the others. ----
     uint32_t chain = blockIdx.x & (NCH - 1);
-    if (tid == 0) s_misc[1] = atomicAdd(&counters[chain * COUNTER_STRIDE], 1u);
+    if (tid == 0) {
+        s_misc[2] = 0u;  // set by the look-back if it has to give up
+        s_misc[1] = atomicAdd(&counters[chain * COUNTER_STRIDE], 1u);
+    }
+    // An earlier pass of this sort gave up (status word set): its output is incomplete, so positions derived
+    // from the upfront histograms no longer bound this pass's writes — do nothing.  Read by another wave, in
+    // flight together with the ticket atomic, so it adds no latency.
+    if (tid == 64) s_misc[3] = ld_agent(status);
     __syncthreads();
+    if (s_misc[3] != STATUS_OK) return;
     uint32_t tile = s_misc[1];
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
@@ -570,7 +586,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             run += c;
         }
         tile_total = run - (tid == 0 ? head : 0u);  // published counts exclude the front dummies
-        st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], (tile_total << 2) | FLAG_REDUCTION);
+        if (!GS_FAULT_TILE(chain, tile))
+            st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], (tile_total << 2) | FLAG_REDUCTION);
         scan_incl = wave_inclusive_scan(run, lane);
         if (lane == 63) s_misc[4 + wave] = scan_incl;
     }
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         uint32_t prev = 0;
         int32_t k = (int32_t)tile;
         uint32_t spins = 0;
-        bool done = (GS_EXP & 1) != 0;
+        bool done = (GS_EXP & 1) != 0, poisoned = false;
 #if GS_EARLY_LOOKBACK
         bool first_trip = true;
 #endif
@@ -638,18 +655,25 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                     const uint32_t f = v[j] & FLAG_MASK;
                     if (f == FLAG_INCLUSIVE) { prev += v[j] >> 2; done = true; }
                     else if (f == FLAG_REDUCTION) { prev += v[j] >> 2; --k; }
+                    else if (f == FLAG_POISON) { poisoned = true; done = true; }  // a predecessor gave up
                     else stalled = true;
                 }
             }
             if (stalled) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_agent(status) != STATUS_OK)) {
-                    st_agent(status, STATUS_TIMEOUT);  // give up: result is invalid, but nothing hangs
+                    poisoned = true;  // give up: nothing hangs, nothing is written with a wrong prefix
                     done = true;
                 }
             }
         }
-        st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], ((prev + tile_total) << 2) | FLAG_INCLUSIVE);
+        if (poisoned) {
+            st_agent(status, STATUS_TIMEOUT);
+            s_misc[2] = 1u;  // this tile must not scatter
+        }
+        if (!GS_FAULT_TILE(chain, tile))
+            st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid],
+                     poisoned ? FLAG_POISON : (((prev + tile_total) << 2) | FLAG_INCLUSIVE));
         s_gbase[tid] = prev - dpre - (tid == 0 ? head : 0u);  // digit 0's real keys start `head` slots into its run
         GS_TRACE(5);
 #if (GS_EXP & 2)
@@ -657,6 +681,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #endif
     }
     __syncthreads();
+    if (s_misc[2] != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----

@@ -395,3 +395,33 @@ def test_sort_is_hip_graph_capturable(gpu, oracle, n, vb):
             np.testing.assert_array_equal(to_host(dv, np.uint32), rv)
     s.check()
     s.close()
+
+
+@pytest.mark.parametrize("key_dtype,kt", [("uint32", 0), ("int32", 1), ("float32", 2)])
+@pytest.mark.parametrize("val_dtype", ["int32", "float32"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_supertest_matrix_native_dtypes(gpu, oracle, key_dtype, kt, val_dtype, order):
+    """D3D12 SuperTestOneSweep (Tests.h:6-186): {asc,desc} x {uint,int,float} keys x {uint,int,float}
+    payloads, on tensors of the NATIVE dtypes; payloads are bit-copied whatever their type."""
+    import torch
+    n = 70001
+    raw = oracle.init_random(n, 17 + kt, 0)
+    if kt == 2:  # make them honest floats: finite, both signs, duplicates
+        raw = (np.random.default_rng(3).standard_normal(n).astype(np.float32) * 1000).round(1).view(np.uint32)
+    payload = (np.arange(n, dtype=np.float32) * 0.5) if val_dtype == "float32" else np.arange(n, dtype=np.int32) - 5
+    tk = torch.from_numpy(raw.view(np.int32).copy()).cuda()
+    if key_dtype == "float32":
+        tk = tk.view(torch.float32)
+    elif key_dtype == "uint32" and hasattr(torch, "uint32"):
+        tk = tk.view(torch.uint32)
+    tv = torch.from_numpy(payload.copy()).cuda()
+    s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS, 4)
+    s.sort(tk, tv)
+    s.check()
+    rk, rv = oracle.std_sort(raw, kt, order, payload.view(np.uint32))
+    np.testing.assert_array_equal(tk.view(torch.int32).cpu().numpy().view(np.uint32), rk)
+    np.testing.assert_array_equal(tv.view(torch.int32).cpu().numpy().view(np.uint32), rv)
+    if kt == 2 and order == 0:
+        f = tk.view(torch.float32).cpu().numpy()
+        assert np.all(f[:-1] <= f[1:])
+    s.close()
