@@ -5,12 +5,14 @@ LIB := gpusorting_amd/lib/libgpusort.so
 SRC := gpusorting_amd/csrc/gpusort_capi.hip
 HDR := gpusorting_amd/csrc/onesweep_kernels.hpp include/gpusort.h
 
-all: $(LIB) gpusorting_amd/lib/libgpusort_fault.so oracle tools
+all: $(LIB) gpusorting_amd/lib/libgpusort_fault.so gpusorting_amd/lib/libgpusort_fault_nofallback.so oracle tools
 $(LIB): $(SRC) $(HDR)
 	@mkdir -p gpusorting_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
 gpusorting_amd/lib/libgpusort_fault.so: $(SRC) $(HDR)
-	$(HIPCC) $(HIPFLAGS) -shared -DGS_EXP=8 -DGS_SPIN_LIMIT=4096 -DGS_NO_TUNING_SHAPES $(SRC) -o $@
+	$(HIPCC) $(HIPFLAGS) -shared -DGS_EXP=8 -DGS_FALLBACK_SPINS=4096 -DGS_NO_TUNING_SHAPES $(SRC) -o $@
+gpusorting_amd/lib/libgpusort_fault_nofallback.so: $(SRC) $(HDR)
+	$(HIPCC) $(HIPFLAGS) -shared -DGS_EXP=8 -DGS_FALLBACK=0 -DGS_SPIN_LIMIT=4096 -DGS_NO_TUNING_SHAPES $(SRC) -o $@
 oracle:
 	$(MAKE) -C oracle
 tools: build/gpusorting_main build/rocprim_compare

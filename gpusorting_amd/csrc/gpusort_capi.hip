@@ -33,16 +33,15 @@ thread_local int g_last_hip_error = 0;
 // ---- tile-shape table -------------------------------------------------------
 // One launcher per (shape, value bytes, key type).  Shape 0 is the default; the
 // others exist for on-device tuning sweeps (u32 keys only).
-using BinLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, const void*, void*,
+using BinLauncher = void (*)(hipStream_t, uint32_t grid, uint32_t*, uint32_t*, void*, void*,
                              uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n,
-                             uint32_t shift, uint32_t reverse);
+                             uint32_t shift, uint32_t mode);
 
 template <int THREADS, int KPT, int VB, int KT, int RANK>
-void launch_bin(hipStream_t s, uint32_t grid, const uint32_t* kin, uint32_t* kout, const void* vin, void* vout,
-                uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n, uint32_t shift,
-                uint32_t reverse) {
-    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, kin,
-                       kout, vin, vout, desc, counters, info, status, n, shift, reverse);
+void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc,
+                uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
+    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, ka, kb,
+                       va, vb, desc, counters, info, status, n, shift, mode);
 }
 
 struct Shape {
@@ -94,6 +93,7 @@ struct gs_onesweep {
     uint32_t value_bytes;
     int shape;
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
+    int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -138,7 +138,7 @@ struct PassPlan {
     uint32_t grid, desc_stride;
 };
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
-                   uint32_t np, PassPlan* plan) {
+                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     const Shape& sh = g_shapes[h->shape];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
@@ -157,7 +157,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_HIST, n, seg_len0, p0, np);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
     hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile);
+                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = tiles + gs::NCH;  // chains end in partial tiles: at most NCH more tiles than n/tile
     plan->desc_stride = desc_stride;
@@ -200,15 +200,20 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     PassPlan plan;
-    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan);
+    // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
+    // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
+    const uint32_t desc_bit = order == GS_ORDER_DESCENDING ? 1u : 0u;
+    const uint32_t dyn = h->skip_passes ? 2u : 0u;
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn);
     if (st != GS_OK) return st;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     for (uint32_t p = 0; p < 4; ++p) {
-        const uint32_t reverse = (order == GS_ORDER_DESCENDING && p == 3) ? 1u : 0u;
-        fn(s, plan.grid, k[p & 1], k[(p + 1) & 1], v[p & 1], v[(p + 1) & 1],
-           h->slab + SLAB_DESC + (size_t)p * plan.desc_stride, h->slab + SLAB_COUNTERS + p * 32 * gs::COUNTER_STRIDE,
-           h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + SLAB_STATUS, n, p * 8, reverse);
+        const uint32_t a = dyn ? 0u : (p & 1u);
+        const uint32_t mode = dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u);
+        fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+           h->slab + SLAB_COUNTERS + p * 32 * gs::COUNTER_STRIDE, h->slab + SLAB_INFO + p * gs::INFO_STRIDE,
+           h->slab + SLAB_STATUS, n, p * 8, mode);
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
     }
     GS_HIP(hipGetLastError());
@@ -282,6 +287,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->rank_mode = 0;
     h->small_path = 1;
     if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
+    h->skip_passes = 1;
+    if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
@@ -346,6 +353,12 @@ gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment build
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on) {
     if (!h) return GS_ERR_ARG;
     h->small_path = on ? 1 : 0;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on) {
+    if (!h) return GS_ERR_ARG;
+    h->skip_passes = on ? 1 : 0;
     return GS_OK;
 }
 
@@ -464,7 +477,8 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
     PassPlan plan;
     st = prologue(h, d_keys_in, n, kt, s, pass, 1, &plan);  // a stand-alone pass: position segments on ANY input
     if (st != GS_OK) return st;
-    fn(s, plan.grid, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
+    fn(s, plan.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
+       const_cast<void*>(d_vals_in), d_vals_out,
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, pass * 8,
        reverse_index ? 1u : 0u);
     GS_HIP(hipGetLastError());
@@ -512,7 +526,8 @@ gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void*
     BinLauncher fn = g_shapes[h->shape].fn[h->rank_mode][vb_index(vb)][h->msd_kt];
     if (!fn) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    fn(s, h->msd_grid, static_cast<const uint32_t*>(d_keys_in), static_cast<uint32_t*>(d_keys_out), d_vals_in, d_vals_out,
+    fn(s, h->msd_grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
+       const_cast<void*>(d_vals_in), d_vals_out,
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, 24, 0u);
     GS_HIP(hipGetLastError());
     h->msd_keys = nullptr;  // the scan state is consumed

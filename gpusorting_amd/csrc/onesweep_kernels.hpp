@@ -67,13 +67,30 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #else
 #define GS_TRACE(slot) do { } while (0)
 #endif
-#ifndef GS_LOOKBACK_BATCH
-#define GS_LOOKBACK_BATCH 1  // descriptor rows fetched per look-back round trip (walks are short with 16 chains)
+// (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
+//  returns a not-yet-final row and the wait moves in front of staging)
+#ifndef GS_ADAPTIVE_BATCH
+#define GS_ADAPTIVE_BATCH 1  // a chain holding a large share of the pass's tiles (skewed digit groups) fetches 4 or 16
+                             // rows per look-back round trip: walk length ~ (tile rate of the chain) / batch
 #endif
-#ifndef GS_EARLY_LOOKBACK
-#define GS_EARLY_LOOKBACK 0  // 1 = issue the first look-back read before the staging phase; measured -4 % (A/B, two
-                             // runs): the early read mostly returns a not-yet-final row and the wait moves in front of staging
+#ifndef GS_FALLBACK
+#define GS_FALLBACK 1  // a look-back that waited FALLBACK_SPINS polls on one row recounts that tile's digits itself
+                       // (whole workgroup, from the pass input) and goes on: no tile ever depends on another
+                       // workgroup's progress for more than a bounded time (reference: SweepCommon.hlsl:297-425,
+                       // EmulatedDeadlocking.cu:159-267).  0 = bounded spin -> POISON -> GS_ERR_TIMEOUT only.
 #endif
+#ifndef GS_FALLBACK_SPINS
+#define GS_FALLBACK_SPINS (1u << 12)  // ~ms: orders of magnitude above any healthy wait, false triggers only cost work
+#endif
+constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
+
+// per-pass flag word info[PASS_FLAGS], written by scan_kernel
+constexpr uint32_t PASS_FLAGS = 2 * (NCH + 1);
+constexpr uint32_t PF_SKEW = 1;    // some digit holds >= n/8 keys: rank with wave-aggregated adds
+constexpr uint32_t PF_SKIP = 2;     // every key has the same digit AND the pass is one of an even number of such
+                                    // passes: the pass is the identity permutation, its workgroups exit at once
+constexpr uint32_t PF_SRC_ALT = 4;  // an odd number of earlier passes ran: this pass reads alt and writes keys
+constexpr uint32_t PF_LAST = 8;     // last pass that runs: applies the descending index reversal
 
 // ---- state slab layout (uint32 words), shared by host and kernels -------------
 //  COUNTERS  tile tickets, [pass][chain]                       (reference m_index)
@@ -136,6 +153,9 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
     *p = v;
 #endif
 }
+
+template <int N>
+struct IntTag { static constexpr int value = N; };
 
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
@@ -287,13 +307,44 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_t* desc, uint32_t* info,
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
-                                                    uint32_t seg_len0, uint32_t tile_keys) {
+                                                    uint32_t seg_len0, uint32_t tile_keys,
+                                                    uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip*/) {
     __shared__ uint32_t s_wtot[4];
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_rowbase[NCH + 1];
+    __shared__ uint32_t s_triv;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
+
+    // ---- which passes run (full sorts only).  A pass whose digit is the same for every key is the identity
+    // permutation; such passes are dropped in PAIRS, so the result still lands in the caller's buffer with no
+    // extra copy and no host round trip: every workgroup of a dropped pass exits on its flag word, every other
+    // pass learns from its flags which buffer it reads.  A descending sort keeps one pass to do the reversal.
+    if (plan & 2u) {
+        if (tid == 0) s_triv = 0;
+        __syncthreads();
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            uint32_t g = 0;
+            for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(qq, tid, x)];
+            if (g == n) atomicOr(&s_triv, 1u << qq);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t triv = s_triv;
+            uint32_t drop = (uint32_t)__popc(triv) & ~1u;
+            if ((plan & 1u) && drop == 4u) drop = 2u;
+            uint32_t skip = 0;
+            for (uint32_t qq = 0; qq < 4 && drop; ++qq)
+                if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
+            const uint32_t run = ~skip & 15u;
+            uint32_t f = 0;
+            if ((skip >> q) & 1u) f |= PF_SKIP;
+            if (__popc(run & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
+            if (run && q == 31u - (uint32_t)__clz(run)) f |= PF_LAST;
+            if (f) atomicOr(&my_info[PASS_FLAGS], f);
+        }
+    }
 
     // segment starts
     if (q == 0) {
@@ -345,7 +396,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
     // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
     const unsigned long long heavy = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
-    if (lane == 0 && heavy) atomicOr(&my_info[2 * (NCH + 1)], 1u);
+    if (lane == 0 && heavy) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
     uint32_t run = base + incl - g;  // dstart[tid]
     for (uint32_t x = 0; x < NCH; ++x) {
         my_desc[(size_t)s_rowbase[x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
@@ -389,11 +440,14 @@ struct BinCfg {
 
 template <int THREADS, int KPT, int VB, int KT, int RANK>
 __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)) void digit_binning_kernel(
-    const uint32_t* keys_in, uint32_t* keys_out, const void* vals_in_, void* vals_out_,
+    uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b,  // the pass reads a and writes b, unless ...
     uint32_t* desc,          // this pass: rows of 256 descriptor words; chain x starts at row_base[x]
     uint32_t* counters,      // this pass: NCH ticket counters
-    const uint32_t* info,    // this pass: seg_start[NCH+1], row_base[NCH+1]
-    uint32_t* status, uint32_t n, uint32_t shift, uint32_t reverse) {
+    const uint32_t* info,    // this pass: seg_start[NCH+1], row_base[NCH+1], flags
+    uint32_t* status, uint32_t n, uint32_t shift,
+    uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
+                    runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
+                    on the last pass that runs (PF_LAST)*/) {
     using Cfg = BinCfg<THREADS, KPT, VB>;
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
@@ -424,14 +478,24 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     uint32_t chain = blockIdx.x & (NCH - 1);
     if (tid == 0) {
         s_misc[2] = 0u;  // set by the look-back if it has to give up
+        s_misc[8] = 0u;  // row a stuck look-back asks the workgroup to recount (GS_FALLBACK)
         s_misc[1] = atomicAdd(&counters[chain * COUNTER_STRIDE], 1u);
     }
     // An earlier pass of this sort gave up (status word set): its output is incomplete, so positions derived
     // from the upfront histograms no longer bound this pass's writes — do nothing.  Read by another wave, in
-    // flight together with the ticket atomic, so it adds no latency.
+    // flight together with the ticket atomic, so it adds no latency.  Same for the pass's flag word.
     if (tid == 64) s_misc[3] = ld_agent(status);
+    if (tid == 128) s_misc[9] = info[PASS_FLAGS];
     __syncthreads();
     if (s_misc[3] != STATUS_OK) return;
+    const uint32_t pflags = s_misc[9];
+    if ((mode & 2u) && (pflags & PF_SKIP)) return;  // identity pass of a full sort
+    const bool swapped = (mode & 2u) && (pflags & PF_SRC_ALT);
+    const uint32_t* keys_in = swapped ? keys_b : keys_a;
+    uint32_t* keys_out = swapped ? keys_a : keys_b;
+    const void* vals_in_ = swapped ? vals_b : vals_a;
+    void* vals_out_ = swapped ? vals_a : vals_b;
+    const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
     uint32_t tile = s_misc[1];
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
@@ -531,7 +595,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         // where the LDS hands same-address lanes of ONE wave-instruction their
         // results in ascending lane order; gs_selftest_lds_atomic_order() probes
         // exactly that on the device before this path is ever selected.
-        if (info[2 * (NCH + 1)] == 0u) {  // uniform per pass (set by scan_kernel)
+        if ((pflags & PF_SKEW) == 0u) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
@@ -600,11 +664,6 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
     }
-#if GS_EARLY_LOOKBACK
-    // first look-back read issued NOW: it flies during the barrier and the staging phase
-    uint32_t early = 0;
-    if (tid < RADIX) early = ld_agent(&cdesc[(size_t)tile * RADIX + tid]);
-#endif
     __syncthreads();
 
     GS_TRACE(3);
@@ -621,66 +680,112 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
 
     // ---- decoupled look-back inside the chain: one digit per thread ----
-    // Row k holds tile k-1's descriptor; row 0 = chain base (INCLUSIVE), so every
-    // walk ends at row 0 at the latest.  GS_LOOKBACK_BATCH rows per round trip.
-    if (tid < RADIX) {
-        uint32_t prev = 0;
-        int32_t k = (int32_t)tile;
-        uint32_t spins = 0;
-        bool done = (GS_EXP & 1) != 0, poisoned = false;
-#if GS_EARLY_LOOKBACK
-        bool first_trip = true;
+    // Row k holds tile k-1's descriptor; row 0 = chain base (INCLUSIVE), so every walk ends at row 0 at the
+    // latest.  NB rows are fetched per round trip: 1 in a balanced chain (walks are ~2 rows with 16 chains), 4 or
+    // 16 in a chain that holds a large share of the pass's tiles (skewed digit groups put most tiles in one
+    // chain; walk length grows with the chain's tile rate and shrinks with the rows in flight).
+    uint32_t nb = 1;
+#if GS_ADAPTIVE_BATCH
+    {
+        const uint32_t share = ((seg_end - (seg_start & ~63u) + TILE - 1) / TILE) * NCH;  // chain's tiles, in NCH-ths of the pass
+        const uint32_t all_tiles = (n + TILE - 1) / TILE;
+        nb = share >= 8u * all_tiles ? 16u : share >= 2u * all_tiles ? 4u : 1u;
+    }
 #endif
-        GS_TRACE(4);
+    uint32_t prev = 0, spins = 0;
+    int32_t k = (int32_t)tile;
+    bool done = (GS_EXP & 1) != 0, poisoned = false, finished = tid >= RADIX;
+    auto walk = [&](auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
         while (!done) {
 #if (GS_EXP & 2)
             ++trace_trips;
 #endif
-            uint32_t v[GS_LOOKBACK_BATCH];
+            uint32_t v[NB];
 #pragma unroll
-            for (int j = 0; j < GS_LOOKBACK_BATCH; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 const int32_t r = k - j < 0 ? 0 : k - j;
-#if GS_EARLY_LOOKBACK
-                if (first_trip && j == 0) { v[0] = early; continue; }  // row `tile`, read before the staging phase
-#endif
                 v[j] = ld_agent(&cdesc[(size_t)r * RADIX + tid]);
             }
-#if GS_EARLY_LOOKBACK
-            first_trip = false;
-#endif
             bool stalled = false;
 #pragma unroll
-            for (int j = 0; j < GS_LOOKBACK_BATCH; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (!done && !stalled) {
                     const uint32_t f = v[j] & FLAG_MASK;
                     if (f == FLAG_INCLUSIVE) { prev += v[j] >> 2; done = true; }
                     else if (f == FLAG_REDUCTION) { prev += v[j] >> 2; --k; }
                     else if (f == FLAG_POISON) { poisoned = true; done = true; }  // a predecessor gave up
-                    else stalled = true;
+                    else stalled = true;  // row k (>= 1: row 0 is seeded before the pass starts) is not there yet
                 }
             }
             if (stalled) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_agent(status) != STATUS_OK)) {
+                ++spins;
+                if (GS_FALLBACK && spins > FALLBACK_SPINS) {
+                    atomicMax(&s_misc[8], (uint32_t)k);  // ask the workgroup to recount tile k-1
+                    return;
+                }
+                if (spins > SPIN_LIMIT || ((spins & 1023u) == 0 && ld_agent(status) != STATUS_OK)) {
                     poisoned = true;  // give up: nothing hangs, nothing is written with a wrong prefix
                     done = true;
                 }
             }
         }
-        if (poisoned) {
-            st_agent(status, STATUS_TIMEOUT);
-            s_misc[2] = 1u;  // this tile must not scatter
+    };
+    GS_TRACE(4);
+    for (;;) {
+        if (!finished) {
+            if (nb == 16u) walk(IntTag<16>{});
+            else if (nb == 4u) walk(IntTag<4>{});
+            else walk(IntTag<1>{});
+            if (done) {
+                finished = true;
+                if (poisoned) {
+                    st_agent(status, STATUS_TIMEOUT);
+                    s_misc[2] = 1u;  // this tile must not scatter
+                }
+                if (!GS_FAULT_TILE(chain, tile))
+                    st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid],
+                             poisoned ? FLAG_POISON : (((prev + tile_total) << 2) | FLAG_INCLUSIVE));
+                s_gbase[tid] = prev - dpre - (tid == 0 ? head : 0u);  // digit 0's real keys start `head` slots into its run
+            }
         }
-        if (!GS_FAULT_TILE(chain, tile))
-            st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid],
-                     poisoned ? FLAG_POISON : (((prev + tile_total) << 2) | FLAG_INCLUSIVE));
-        s_gbase[tid] = prev - dpre - (tid == 0 ? head : 0u);  // digit 0's real keys start `head` slots into its run
-        GS_TRACE(5);
-#if (GS_EXP & 2)
-        if (tid == 0) trace[7] = trace_trips | (chain << 16) | (1u << 31);
-#endif
+        __syncthreads();
+        if (!GS_FALLBACK) break;
+        const uint32_t fb_row = s_misc[8];  // uniform
+        if (fb_row == 0u) break;
+        // ---- fallback: some digit's walk waited FALLBACK_SPINS polls on row fb_row.  The whole workgroup
+        // recounts that tile's digits from the pass input (which nobody writes during the pass), offers the
+        // counts to everyone as REDUCTION descriptors (compare-and-swap on NOT_READY: whatever the owner
+        // publishes later is the same count or its inclusive form), and the stuck walks go on below that row.
+        // The per-wave counters are dead once the stage is written (the barrier above), so they are the scratch.
+        {
+            uint32_t* s_fb = s_whist;
+            const uint32_t fbase = (seg_start & ~63u) + (fb_row - 1u) * TILE;
+            const uint32_t flo = fbase > seg_start ? fbase : seg_start;
+            const uint32_t fhi = (seg_end - fbase < TILE) ? seg_end : fbase + TILE;
+            for (uint32_t i = tid; i < RADIX; i += THREADS) s_fb[i] = 0;
+            if (tid == 0) s_misc[8] = 0u;
+            __syncthreads();
+            for (uint32_t idx = flo + tid; idx < fhi; idx += THREADS)
+                atomicAdd(&s_fb[(to_bits<KT>(keys_in[idx]) >> shift) & 255u], 1u);
+            __syncthreads();
+            if (!finished) {
+                if (k == (int32_t)fb_row) {
+                    const uint32_t c = s_fb[tid];
+                    atomicCAS(&cdesc[(size_t)fb_row * RADIX + tid], 0u, (c << 2) | FLAG_REDUCTION);
+                    prev += c;
+                    --k;
+                }
+                spins = 0;
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
+    GS_TRACE(5);
+#if (GS_EXP & 2)
+    if (tid == 0) trace[7] = trace_trips | (chain << 16) | (1u << 31);
+#endif
     if (s_misc[2] != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly

@@ -128,6 +128,10 @@ class OneSweep:
     def set_small_path(self, on: bool) -> None:
         check(self._lib.gs_onesweep_set_small_path(self._h, 1 if on else 0), "gs_onesweep_set_small_path")
 
+    def set_skip_passes(self, on: bool) -> None:
+        """Identity passes (one digit value for all keys) are dropped in pairs on the device (default on)."""
+        check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")
+
     def _alts(self, n: int, values: torch.Tensor | None):
         if self._alt_keys is None or self._alt_keys.numel() < n:
             self._alt_keys = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)

@@ -114,6 +114,12 @@ gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
 /* n <= 8192 is sorted by ONE workgroup in one launch (all four passes in LDS) unless this is
  * switched off (tests use 0 to push small sizes through the tiled path as well). */
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
+/* A pass whose digit is the same for every key (e.g. the upper bytes of 16-bit keys) is the
+ * identity permutation.  The Scan kernel sees that in the histogram and drops such passes in
+ * pairs, on the device, with no host round trip (the reference always runs
+ * four passes).  Results are identical either way; 0 runs all four passes.  Default 1;
+ * env GPUSORT_SKIP_PASSES=0/1 sets it at create. */
+gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);

@@ -1,5 +1,11 @@
-"""Fault injection (-m gpu): a build in which one tile never publishes its descriptor (the reference's
-analogue: EmulatedDeadlocking.cu:36-37,339-345).  The sort must return — no hang — and report the timeout."""
+"""Fault injection (-m gpu): builds in which one tile never publishes its descriptor, as if its workgroup had
+stalled (the reference's analogue: EmulatedDeadlocking.cu:36-37,339-345).
+  * libgpusort_fault.so            look-back fallback ON (the product's default): the successors recount the
+                                   silent tile themselves, the sort is exact and reports GS_OK
+                                   (reference: SweepCommon.hlsl:297-425 "look-back with fallback")
+  * libgpusort_fault_nofallback.so fallback OFF: the sort must return — no hang — report GS_ERR_TIMEOUT and
+                                   never write a key with a wrong prefix
+"""
 import os
 import subprocess
 import sys
@@ -9,13 +15,45 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAULT_LIB = os.path.join(ROOT, "gpusorting_amd", "lib", "libgpusort_fault.so")
+LIBDIR = os.path.join(ROOT, "gpusorting_amd", "lib")
+
+
+def _run(lib, code):
+    path = os.path.join(LIBDIR, lib)
+    if not os.path.exists(path):
+        pytest.fail(f"{lib} missing: run __graft_entry__.build()")
+    env = dict(os.environ, GPUSORT_LIB=path)
+    out = subprocess.run([sys.executable, "-c", textwrap.dedent(code) % ROOT], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
+    out = _run("libgpusort_fault.so", """
+        import sys, time, torch
+        sys.path.insert(0, %r)
+        import gpusorting_amd as g
+        for n, pairs in ((1 << 22, False), ((1 << 22) + 12345, True)):   # tile 5 of chain 3 stays silent in every pass
+            k = torch.empty(n, dtype=torch.int32, device="cuda")
+            g.init_random(k, 10, 0)
+            v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+            ref = torch.sort(k.to(torch.int64) & 0xffffffff, stable=True)
+            s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+            t0 = time.time()
+            s.sort(k, v)
+            s.check()                      # raises on GS_ERR_TIMEOUT
+            ok = bool(((k.to(torch.int64) & 0xffffffff) == ref.values).all().item())
+            if pairs:
+                ok = ok and bool((v.to(torch.int64) == ref.indices).all().item())
+            print("RESULT", "exact" if ok else "WRONG", "seconds", round(time.time() - t0, 3))
+    """)
+    assert out.count("RESULT exact") == 2, out
+    assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
 
 
 def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
-    if not os.path.exists(FAULT_LIB):
-        pytest.fail("libgpusort_fault.so missing: run __graft_entry__.build()")
-    code = textwrap.dedent("""
+    out = _run("libgpusort_fault_nofallback.so", """
         import sys, time, torch
         sys.path.insert(0, %r)
         import gpusorting_amd as g
@@ -35,11 +73,8 @@ def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
         ref = torch.sort(m).values
         s2 = g.OneSweep(1000); s2.sort(m); torch.cuda.synchronize()
         print("SMALL", bool((m == ref).all().item()))
-    """) % ROOT
-    env = dict(os.environ, GPUSORT_LIB=FAULT_LIB)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "RESULT status 4" in out.stdout, out.stdout + out.stderr[-500:]   # GS_ERR_TIMEOUT
-    secs = float(out.stdout.split("seconds")[1].split()[0])
+    """)
+    assert "RESULT status 4" in out, out   # GS_ERR_TIMEOUT
+    secs = float(out.split("seconds")[1].split()[0])
     assert secs < 20.0
-    assert "SMALL True" in out.stdout
+    assert "SMALL True" in out

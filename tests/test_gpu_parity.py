@@ -425,3 +425,52 @@ def test_supertest_matrix_native_dtypes(gpu, oracle, key_dtype, kt, val_dtype, o
         f = tk.view(torch.float32).cpu().numpy()
         assert np.all(f[:-1] <= f[1:])
     s.close()
+
+
+_MASKS = [0x0000FFFF, 0x00FFFFFF, 0x000000FF, 0xFF00FF00, 0xFFFF0000, 0x00FF0000, 0x12000000, 0x00000000]
+
+
+@pytest.mark.parametrize("skip", [True, False])
+@pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (0, 0, 1), (4, 0, 0), (4, 0, 1), (8, 1, 1), (0, 2, 0), (4, 2, 1)])
+def test_identity_passes_dropped_on_device(gpu, oracle, P, skip, vb, kt, order):
+    """passes whose digit is the same for every key are dropped (in pairs, decided by the Scan
+    kernel) — results must be what the full four passes give, including the descending reversal of values
+    of equal keys, which needs a pass to carry it even when no digit varies."""
+    n = 5 * P + 77
+    base = oracle.init_random(n, 4242, 0)
+    for mask in _MASKS:
+        keys = (base & np.uint32(mask)) | np.uint32(0x5A000000 & ~mask)   # constant bytes are not all zero
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        s = gpu.OneSweep(n, order, kt, gpu.MODE_KEYS_ONLY if not vb else gpu.MODE_PAIRS, vb)
+        s.set_skip_passes(skip)
+        dk = to_dev(keys)
+        dv = None if vals is None else to_dev(vals)
+        s.sort(dk, dv)
+        s.check()
+        if vals is None:
+            np.testing.assert_array_equal(to_host(dk, np.uint32), oracle.std_sort(keys, kt, order), err_msg=hex(mask))
+        else:
+            rk, rv = oracle.std_sort(keys, kt, order, vals)
+            np.testing.assert_array_equal(to_host(dk, np.uint32), rk, err_msg=hex(mask))
+            np.testing.assert_array_equal(to_host(dv, vals.dtype), rv, err_msg=hex(mask))
+        s.close()
+
+
+def test_dropped_passes_cost_nothing(gpu):
+    """16-bit keys: passes 2 and 3 must be launches of workgroups that exit at once."""
+    import torch
+    n = 1 << 24
+    k = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device="cuda")
+    s = gpu.OneSweep(n)
+    s.set_profiling(True)
+    best = None
+    for _ in range(3):
+        kk = k.clone()
+        s.sort(kk)
+        torch.cuda.synchronize()
+        p = s.get_profile()
+        best = p if best is None or p["total"] < best["total"] else best
+    assert bool((kk[1:] >= kk[:-1]).all().item())
+    real = min(best["pass0"], best["pass1"])
+    assert max(best["pass2"], best["pass3"]) < 0.5 * real, best
+    s.close()
