@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
                                                     uint32_t seg_len0, uint32_t tile_keys,
                                                     uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip*/) {
-    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_wtot[2][4];
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_rowbase[NCH + 1];
     __shared__ uint32_t s_triv;
@@ -317,50 +317,69 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
 
+    // Everything this workgroup needs from global memory, in ONE round trip: thread d's row of every joint
+    // histogram (rows of passes that were not counted are zero).  The kernel is a serial step of every sort;
+    // with the loads strung out behind each other it took 11 us.
+    uint32_t hq[NCH], g_all[4], g = 0, gprev = 0;
+    {
+        uint32_t h[4][NCH];
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (uint32_t x = 0; x < NCH; ++x) h[qq][x] = hist[hist_index(qq, tid, x)];
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            g_all[qq] = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < NCH; ++x) g_all[qq] += h[qq][x];
+            if (qq == q) g = g_all[qq];
+            if (qq + 1 == q) gprev = g_all[qq];
+        }
+#pragma unroll
+        for (uint32_t x = 0; x < NCH; ++x) hq[x] = q == 0 ? h[0][x] : q == 1 ? h[1][x] : q == 2 ? h[2][x] : h[3][x];
+    }
+    if (tid == 0) s_triv = 0;
+    __syncthreads();
+
     // ---- which passes run (full sorts only).  A pass whose digit is the same for every key is the identity
     // permutation; such passes are dropped in PAIRS, so the result still lands in the caller's buffer with no
     // extra copy and no host round trip: every workgroup of a dropped pass exits on its flag word, every other
     // pass learns from its flags which buffer it reads.  A descending sort keeps one pass to do the reversal.
     if (plan & 2u) {
-        if (tid == 0) s_triv = 0;
-        __syncthreads();
-        for (uint32_t qq = 0; qq < 4; ++qq) {
-            uint32_t g = 0;
-            for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(qq, tid, x)];
-            if (g == n) atomicOr(&s_triv, 1u << qq);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t triv = s_triv;
-            uint32_t drop = (uint32_t)__popc(triv) & ~1u;
-            if ((plan & 1u) && drop == 4u) drop = 2u;
-            uint32_t skip = 0;
-            for (uint32_t qq = 0; qq < 4 && drop; ++qq)
-                if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
-            const uint32_t run = ~skip & 15u;
-            uint32_t f = 0;
-            if ((skip >> q) & 1u) f |= PF_SKIP;
-            if (__popc(run & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
-            if (run && q == 31u - (uint32_t)__clz(run)) f |= PF_LAST;
-            if (f) atomicOr(&my_info[PASS_FLAGS], f);
-        }
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; ++qq)
+            if (g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
+    }
+    // digit scans of this pass's totals and (for the segment starts) of the previous digit's totals
+    const uint32_t incl = wave_inclusive_scan(g, lane);
+    const uint32_t incl_prev = wave_inclusive_scan(gprev, lane);
+    if (lane == 63) { s_wtot[0][wave] = incl; s_wtot[1][wave] = incl_prev; }
+    __syncthreads();
+    uint32_t base = 0, base_prev = 0;
+    for (uint32_t w = 0; w < wave; ++w) { base += s_wtot[0][w]; base_prev += s_wtot[1][w]; }
+    if ((plan & 2u) && tid == 0) {
+        const uint32_t triv = s_triv;
+        uint32_t drop = (uint32_t)__popc(triv) & ~1u;
+        if ((plan & 1u) && drop == 4u) drop = 2u;
+        uint32_t skip = 0;
+        for (uint32_t qq = 0; qq < 4 && drop; ++qq)
+            if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
+        const uint32_t run = ~skip & 15u;
+        uint32_t f = 0;
+        if ((skip >> q) & 1u) f |= PF_SKIP;
+        if (__popc(run & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
+        if (run && q == 31u - (uint32_t)__clz(run)) f |= PF_LAST;
+        if (f) atomicOr(&my_info[PASS_FLAGS], f);
     }
 
-    // segment starts
+    // segment starts: q == 0 position segments; q >= 1 starts of the digit-(q-1) groups
     if (q == 0) {
         if (tid <= NCH) {
             const unsigned long long s = (unsigned long long)tid * seg_len0;
             s_cum[tid] = s < n ? (uint32_t)s : n;
         }
     } else {
-        uint32_t g = 0;
-        for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(q - 1, tid, x)];
-        const uint32_t incl = wave_inclusive_scan(g, lane);
-        if (lane == 63) s_wtot[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t w = 0; w < wave; ++w) base += s_wtot[w];
-        s_cum[tid + 1] = base + incl;  // keys with previous digit <= tid
+        s_cum[tid + 1] = base_prev + incl_prev;  // keys with previous digit <= tid
         if (tid == 0) s_cum[0] = 0;
         __syncthreads();
         uint32_t v = 0;
@@ -369,14 +388,15 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         if (tid <= NCH) s_cum[tid] = v;  // compact: s_cum[x] = start of digit group x
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t rb = 0;
-        for (uint32_t x = 0; x < NCH; ++x) {
-            s_rowbase[x] = rb;
-            const uint32_t a = s_cum[x] & ~63u;  // the chain's tile grid starts on a 256-byte boundary
-            rb += (s_cum[x + 1] - a + tile_keys - 1) / tile_keys + 1u;
+    // first descriptor row of every chain: a wave-level scan over the chains' row counts
+    if (wave == 0) {
+        uint32_t rows = 0;
+        if (lane < NCH) {
+            const uint32_t a = s_cum[lane] & ~63u;  // the chain's tile grid starts on a 256-byte boundary
+            rows = (s_cum[lane + 1] - a + tile_keys - 1) / tile_keys + 1u;
         }
-        s_rowbase[NCH] = rb;
+        const uint32_t rincl = wave_inclusive_scan(rows, lane);
+        if (lane <= NCH) s_rowbase[lane] = rincl - rows;  // lane NCH: rows == 0 -> the total
     }
     __syncthreads();
     if (tid <= NCH) {
@@ -384,23 +404,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         my_info[NCH + 1 + tid] = s_rowbase[tid];
     }
 
-    // digit starts and chain bases
-    uint32_t g = 0;
-    for (uint32_t x = 0; x < NCH; ++x) g += hist[hist_index(q, tid, x)];
-    __syncthreads();
-    const uint32_t incl = wave_inclusive_scan(g, lane);
-    if (lane == 63) s_wtot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; ++w) base += s_wtot[w];
     // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
     // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
     const unsigned long long heavy = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
     if (lane == 0 && heavy) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
+    // digit starts and chain bases
     uint32_t run = base + incl - g;  // dstart[tid]
+#pragma unroll
     for (uint32_t x = 0; x < NCH; ++x) {
         my_desc[(size_t)s_rowbase[x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
-        run += hist[hist_index(q, tid, x)];
+        run += hq[x];
     }
 }
 
@@ -552,10 +565,18 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         // Masked slots become dummy keys that are never written: in FRONT of the segment
         // all-zero bits (digit 0: being first in array order they open the digit-0 run, stage
         // slots [0, head)), BEHIND it all-one bits (digit 255: they close the last run).
+        // The loads are UNCONDITIONAL on a clamped index and masked afterwards: guarded loads are issued one
+        // at a time (a wait after each), which made every partial tile ~20 us — the whole pass at mid sizes,
+        // where each chain is one or two partial tiles.
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = my_base + i * 64u;
-            key[i] = (idx >= lo && idx < hi) ? to_bits<KT>(ld_stream<VB == 0>(keys_in + idx)) : (idx < lo ? 0u : 0xffffffffu);
+            key[i] = ld_stream<VB == 0>(keys_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : to_bits<KT>(key[i]));
         }
     }
 
@@ -595,12 +616,24 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         // where the LDS hands same-address lanes of ONE wave-instruction their
         // results in ascending lane order; gs_selftest_lds_atomic_order() probes
         // exactly that on the device before this path is ever selected.
-        if ((pflags & PF_SKEW) == 0u) {  // uniform per pass (set by scan_kernel)
+        if ((pflags & PF_SKEW) == 0u && full) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
                 const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 offp[i >> 1] |= r << (16 * (i & 1));
+            }
+        } else if ((pflags & PF_SKEW) == 0u) {
+            // Partial tile: the dummies behind the segment take no part at all (mask_tail below).  Ranked like
+            // keys they would put up to 64 lanes x KPT rounds on the single counter of digit 255 — ~12 us, on
+            // the last tile of every chain: the tail of every pass, and most of a pass at mid sizes.
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                if (my_base + i * 64u < hi) {
+                    const uint32_t d = (key[i] >> shift) & 255u;
+                    const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    offp[i >> 1] |= r << (16 * (i & 1));
+                }
             }
         } else {
             // Skewed pass: the lanes holding the wave's remembered dominant digit take ONE add of
@@ -668,11 +701,13 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 
     GS_TRACE(3);
     // ---- stage keys in LDS, sorted by digit (stable) ----
+    // mask_tail: the tile's trailing dummies were not ranked (above) and are not staged
+    const bool mask_tail = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t d = (key[i] >> shift) & 255u;
         const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
-        s_stage[lpos] = key[i];
+        if (!mask_tail || my_base + i * 64u < hi) s_stage[lpos] = key[i];
         if constexpr (VB != 0) {  // values follow the same positions later
             if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
             else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
@@ -793,10 +828,15 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     V val[VB != 0 ? KPT : 1];
     if constexpr (VB != 0) {
         const V* vals_in = reinterpret_cast<const V*>(vals_in_);
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = my_base + i * 64u;
-            val[i] = (full || (idx >= lo && idx < hi)) ? ld_stream<false>(vals_in + idx) : V(0);
+            for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
+        } else {  // clamped, unconditional (see the key loads); slots outside [lo, hi) are never written out
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = my_base + i * 64u;
+                val[i] = ld_stream<false>(vals_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+            }
         }
     }
 
@@ -824,7 +864,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         V* s_vstage = reinterpret_cast<V*>(s_raw);
         __syncthreads();  // everyone is done reading the key stage
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
+        for (int i = 0; i < KPT; ++i)
+            if (!mask_tail || my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -865,12 +906,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
 
     uint32_t key[KPT];
     V val[VB != 0 ? KPT : 1];
+    // unconditional loads on a clamped index, masked afterwards (guarded loads are issued one at a time)
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t idx = my_base + i * 64u;
-        key[i] = idx < n ? to_bits<KT>(keys[idx]) : 0xffffffffu;
-        if constexpr (VB != 0) val[i] = idx < n ? reinterpret_cast<const V*>(vals_)[idx] : V(0);
+        const uint32_t ci = idx < n ? idx : n - 1u;
+        key[i] = keys[ci];
+        if constexpr (VB != 0) val[i] = reinterpret_cast<const V*>(vals_)[ci];
     }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < n ? to_bits<KT>(key[i]) : 0xffffffffu;
 
 #pragma unroll 1
     for (uint32_t shift = 0; shift < 32; shift += 8) {
@@ -898,10 +943,14 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
                 off[i] = pre + below;
             }
         } else {
+            // slots >= n take no part (the dummies would all meet on the counter of digit 255, 64 lanes deep,
+            // in every pass); they stay behind the n real keys, so validity is a property of the slot
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
-                off[i] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                off[i] = 0;
+                if (my_base + i * 64u < n)
+                    off[i] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __syncthreads();
@@ -928,8 +977,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
-            s_stage[lpos] = key[i];
-            if constexpr (VB != 0) s_vstage[lpos] = val[i];
+            if (RANK == 0 || my_base + i * 64u < n) {
+                s_stage[lpos] = key[i];
+                if constexpr (VB != 0) s_vstage[lpos] = val[i];
+            }
         }
         __syncthreads();
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-tile phase timing of the DigitBinningPass (needs the GS_EXP=2 build:
-GPUSORT_LIB=gpusorting_amd/lib/libgpusort_trace.so).  Usage: trace_tiles.py [log2=28] [TxK=512x32]"""
+GPUSORT_LIB=gpusorting_amd/lib/libgpusort_trace.so).  Usage: trace_tiles.py [log2=28] [TxK=512x32] [entropy_preset_index=0]"""
 import ctypes as C
 import os
 import sys
@@ -17,6 +17,7 @@ def main():
     a = sys.argv[1:]
     log2 = int(a[0]) if a else 28
     t, k = (int(x) for x in (a[1] if len(a) > 1 else "512x32").split("x"))
+    preset = int(a[2]) if len(a) > 2 else 0
     n = 1 << log2
     lib = _lib.load()
     lib.gs_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
@@ -28,13 +29,13 @@ def main():
     tr = torch.zeros(4 * grid * 8, dtype=torch.int32, device="cuda")
     lib.gs_debug_set_trace(s._h, tr.data_ptr())
     for rep in range(2):
-        g.init_random(keys, 10 + rep, 0)
+        g.init_random(keys, 10 + rep, preset)
         torch.cuda.synchronize()
         s.sort(keys, alt_keys=alt)
         s.check()
     d = tr.cpu().numpy().view(np.uint32).reshape(4, grid, 8).astype(np.int64)
     names = ["claim", "load+rank", "reduce+RED+fold", "stage", "lookback", "scatter", "tile total"]
-    print(f"shape {t}x{k} blocks/pass={grid} (10 ns ticks -> us; thread 0 of each workgroup)")
+    print(f"entropy preset {preset + 1}; shape {t}x{k} blocks/pass={grid} (10 ns ticks -> us; thread 0 of each workgroup)")
     for p in range(4):
         x = d[p]
         x = x[(x[:, 7] >> 31) == 1]
