@@ -73,6 +73,11 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #define GS_ADAPTIVE_BATCH 1  // a chain holding a large share of the pass's tiles (skewed digit groups) fetches 4 or 16
                              // rows per look-back round trip: walk length ~ (tile rate of the chain) / batch
 #endif
+#ifndef GS_NB_HEAVY
+#define GS_NB_HEAVY 16u  // rows per round trip in a chain that holds at least half of the pass's tiles (64 measured
+                         // worse: 9.8 us look-back per tile vs 6.6 — the wait in a crowded chain is for predecessors
+                         // to publish at all, not for the walk; see DESIGN.md on skew)
+#endif
 #ifndef GS_FALLBACK
 #define GS_FALLBACK 1  // a look-back that waited FALLBACK_SPINS polls on one row recounts that tile's digits itself
                        // (whole workgroup, from the pass input) and goes on: no tile ever depends on another
@@ -522,11 +527,29 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             bool open = false;
             if (lane < NCH) {
                 const uint32_t s0 = info[lane], s1 = info[lane + 1];
-                tiles_x = (s1 - (s0 & ~63u) + TILE - 1) / TILE;
-                open = (s1 != s0) && ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
+                tiles_x = s1 != s0 ? (s1 - (s0 & ~63u) + TILE - 1) / TILE : 0u;
+                open = ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(open);
             uint32_t got_x = 0, got_t = 0xffffffffu;
+            // First try: a chain drawn in proportion to the chains' tile counts (Fibonacci hashing of the
+            // workgroup id: consecutive ids spread evenly over the cumulative tile range).  With skewed
+            // digit groups most workgroups land here — their own chain is tiny — and the big chains still
+            // get their workgroups interleaved, in one atomic instead of a scan of the open chains.
+            if (m) {
+                const uint32_t incl = wave_inclusive_scan(tiles_x, lane);
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t v = (uint32_t)(((unsigned long long)(blockIdx.x * 0x9E3779B1u) * total) >> 32);
+                const unsigned long long ge = __builtin_amdgcn_ballot_w64(lane < NCH && incl > v);
+                const uint32_t x = ge ? (uint32_t)__builtin_ctzll(ge) : 0u;
+                if ((m >> x) & 1ull) {
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t < __builtin_amdgcn_readlane(tiles_x, x)) { got_x = x; got_t = t; m = 0; }
+                    else m &= ~(1ull << x);
+                }
+            }
             while (m) {  // wave-uniform: try the open chains one by one, starting after our own
                 const unsigned long long rot = (m >> chain) | (m << ((NCH - chain) & 63));
                 const uint32_t x = (chain + (uint32_t)__builtin_ctzll(rot & ((1ull << NCH) - 1ull))) & (NCH - 1);
@@ -636,36 +659,49 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 }
             }
         } else {
-            // Skewed pass: the lanes holding the wave's remembered dominant digit take ONE add of
-            // their popcount (issued by their first lane) and rank themselves with mbcnt; all other
-            // lanes use the per-lane atomic.  The group contains ALL lanes of that digit, so group and
-            // per-lane adds never meet on one counter inside a round; rounds are ordered by the
-            // in-order LDS queue.  The guess is relearned from the first lane whenever it covers < 8 lanes.
+            // Skewed pass: the lanes holding the wave's remembered dominant digit take ONE add of their
+            // popcount (issued by their first lane) and rank themselves with mbcnt; all other lanes add 1 for
+            // themselves — in the SAME ds_add_rtn instruction (the group contains ALL lanes of that digit, so
+            // group and per-lane adds never meet on one counter inside a round; rounds are ordered by the in-order
+            // LDS queue).  The guess is relearned from the first lane whenever it covers < 8 lanes; that decision
+            // needs ballots only, never a returned value, so the atomics of SKEW_CHUNK rounds are issued back to
+            // back and resolved together (one dependent LDS round trip per chunk instead of two per key).
+            constexpr int SKEW_CHUNK = 8;
+            static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
             uint32_t sticky = 0xffffffffu;  // wave-uniform
-#pragma unroll 4
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
-                unsigned long long m = __builtin_amdgcn_ballot_w64(d == sticky);
-                if (__popcll(m) < 8) {
-                    sticky = __builtin_amdgcn_readfirstlane(d);
-                    m = __builtin_amdgcn_ballot_w64(d == sticky);
+#pragma unroll
+            for (int c = 0; c < KPT; c += SKEW_CHUNK) {
+                uint32_t ret[SKEW_CHUNK];
+                unsigned long long grp[SKEW_CHUNK];  // wave-uniform: lanes aggregated in round j (0 = none)
+#pragma unroll
+                for (int j = 0; j < SKEW_CHUNK; ++j) {
+                    const uint32_t d = (key[c + j] >> shift) & 255u;
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(d == sticky);
+                    if (__popcll(m) < 8) {
+                        sticky = __builtin_amdgcn_readfirstlane(d);
+                        m = __builtin_amdgcn_ballot_w64(d == sticky);
+                        if (__popcll(m) < 8) m = 0;
+                    }
+                    grp[j] = m;
+                    const bool in_grp = m != 0 && d == sticky;
+                    const bool leader = in_grp && __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
+                    ret[j] = 0;
+                    if (!in_grp || leader)
+                        ret[j] = __hip_atomic_fetch_add(&whist[d], leader ? (uint32_t)__popcll(m) : 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                uint32_t r;
-                if (__popcll(m) >= 8) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                    uint32_t base = 0;
-                    if (lane == l)
-                        base = __hip_atomic_fetch_add(&whist[sticky], (uint32_t)__popcll(m), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                    base = __builtin_amdgcn_readlane(base, l);
-                    if (d == sticky)
-                        r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    else
-                        r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int j = 0; j < SKEW_CHUNK; ++j) {
+                    const int i = c + j;
+                    uint32_t r = ret[j];
+                    const unsigned long long m = grp[j];
+                    if (m != 0) {  // uniform
+                        const uint32_t base = __builtin_amdgcn_readlane(ret[j], (uint32_t)__builtin_ctzll(m));
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if ((m >> lane) & 1ull) r = base + below;
+                    }
+                    if (i & 1) offp[i >> 1] |= r << 16; else offp[i >> 1] |= r;
                 }
-                if (i & 1) offp[i >> 1] |= r << 16; else offp[i >> 1] |= r;
             }
         }
     }
@@ -724,7 +760,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     {
         const uint32_t share = ((seg_end - (seg_start & ~63u) + TILE - 1) / TILE) * NCH;  // chain's tiles, in NCH-ths of the pass
         const uint32_t all_tiles = (n + TILE - 1) / TILE;
-        nb = share >= 8u * all_tiles ? 16u : share >= 2u * all_tiles ? 4u : 1u;
+        nb = share >= 8u * all_tiles ? GS_NB_HEAVY : share >= 4u * all_tiles ? 16u : share >= 2u * all_tiles ? 4u : 1u;
     }
 #endif
     uint32_t prev = 0, spins = 0;
@@ -770,7 +806,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     GS_TRACE(4);
     for (;;) {
         if (!finished) {
-            if (nb == 16u) walk(IntTag<16>{});
+            if (nb == 64u) walk(IntTag<64>{});
+            else if (nb == 16u) walk(IntTag<16>{});
             else if (nb == 4u) walk(IntTag<4>{});
             else walk(IntTag<1>{});
             if (done) {
