@@ -34,14 +34,15 @@ thread_local int g_last_hip_error = 0;
 // One launcher per (shape, value bytes, key type).  Shape 0 is the default; the
 // others exist for on-device tuning sweeps (u32 keys only).
 using BinLauncher = void (*)(hipStream_t, uint32_t grid, uint32_t*, uint32_t*, void*, void*,
-                             uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n,
-                             uint32_t shift, uint32_t mode);
+                             uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* hsub, uint32_t* status,
+                             uint32_t n, uint32_t shift, uint32_t mode);
 
 template <int THREADS, int KPT, int VB, int KT, int RANK>
 void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc,
-                uint32_t* counters, const uint32_t* info, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
+                uint32_t* counters, const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift,
+                uint32_t mode) {
     hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, ka, kb,
-                       va, vb, desc, counters, info, status, n, shift, mode);
+                       va, vb, desc, counters, info, hsub, status, n, shift, mode);
 }
 
 struct Shape {
@@ -94,6 +95,7 @@ struct gs_onesweep {
     int shape;
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
+    int heavy;       // heavy-value position slices: -1 auto (keys-only sorts), 0 off, 1 on
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -112,7 +114,7 @@ namespace {
 
 size_t slab_words_for(uint32_t max_keys) {
     const size_t max_tiles = div_up(max_keys, MIN_TILE);
-    return SLAB_DESC + 4 * (max_tiles + 2 * gs::NCH + 1) * (size_t)gs::RADIX;
+    return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
 }
 
 using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t);
@@ -143,7 +145,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const Shape& sh = g_shapes[h->shape];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
-    const uint32_t rows = tiles + 2 * gs::NCH + 1;  // every chain: its tiles (+1 partial) + row 0
+    const uint32_t rows = tiles + 2 * gs::MAXCH + 2;  // every chain: its tiles (+1 partial) + row 0
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = SLAB_DESC + (size_t)np * desc_stride;
     // position segments of the first pass: equal, multiples of the histogram chunk
@@ -159,7 +161,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
                        h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
-    plan->grid = tiles + gs::NCH;  // chains end in partial tiles: at most NCH more tiles than n/tile
+    plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->desc_stride = desc_stride;
     return GS_OK;
 }
@@ -204,7 +206,11 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
     const uint32_t desc_bit = order == GS_ORDER_DESCENDING ? 1u : 0u;
     const uint32_t dyn = h->skip_passes ? 2u : 0u;
-    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn);
+    // bit 2: the heavy-value layout may be used (its counts are gathered in the LDS-atomic ranking path only)
+    // (measured: it pays for keys-only sorts; with values the counting costs more than the balanced chains
+    // gain, profiles/r01_entropy_*): GPUSORT_HEAVY=0/1 overrides
+    const bool heavy = dyn && h->rank_mode == 1 && (h->heavy < 0 ? vb == 0 : h->heavy != 0);
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u));
     if (st != GS_OK) return st;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
@@ -212,8 +218,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         const uint32_t a = dyn ? 0u : (p & 1u);
         const uint32_t mode = dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u);
         fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-           h->slab + SLAB_COUNTERS + p * 32 * gs::COUNTER_STRIDE, h->slab + SLAB_INFO + p * gs::INFO_STRIDE,
-           h->slab + SLAB_STATUS, n, p * 8, mode);
+           h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
+           h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
     }
     GS_HIP(hipGetLastError());
@@ -287,6 +293,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->rank_mode = 0;
     h->small_path = 1;
     if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
+    h->heavy = -1;
+    if (const char* env = getenv("GPUSORT_HEAVY")) h->heavy = atoi(env) ? 1 : 0;
     h->skip_passes = 1;
     if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
     h->profiling = 0;
@@ -312,7 +320,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     }
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
-    if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_HIST * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_DESC * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
@@ -479,7 +487,7 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
     if (st != GS_OK) return st;
     fn(s, plan.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
-       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, pass * 8,
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, pass * 8,
        reverse_index ? 1u : 0u);
     GS_HIP(hipGetLastError());
     if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
@@ -528,7 +536,7 @@ gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     fn(s, h->msd_grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
-       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + SLAB_STATUS, n, 24, 0u);
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, 24, 0u);
     GS_HIP(hipGetLastError());
     h->msd_keys = nullptr;  // the scan state is consumed
     h->profile_pending = false;

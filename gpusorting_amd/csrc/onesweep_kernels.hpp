@@ -89,27 +89,61 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #endif
 constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 
-// per-pass flag word info[PASS_FLAGS], written by scan_kernel
-constexpr uint32_t PASS_FLAGS = 2 * (NCH + 1);
+#ifndef GS_HEAVY
+#define GS_HEAVY 1  // a digit value holding more than half of the keys gets its region of the NEXT pass's input split into NCH
+                    // position sub-chains; the joint counts those chains need are gathered by the pass that writes
+                    // the region (see "heavy digit" in DESIGN.md).  0 = digit-group chains only.
+#endif
+#ifndef GS_HEAVY_SHARE
+#define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
+                           // gain nothing over the digit-group chains and the counting still costs
+#endif
+#ifndef GS_HEAVY_MIN_KEYS
+#define GS_HEAVY_MIN_KEYS (1u << 22)  // below this a sub-chain would be shorter than a few tiles
+#endif
+// Chains of a pass.  Normal: chain c < NCH = position segment (first pass) or group of the previous digit.
+// Heavy (digit value h of the previous digit holds more than half of the keys): chains 0..NCH-1 = equal position slices of h's
+// region; NCH + x = digit group x (group x_h = h >> 4 keeps only its digits below h); 2*NCH = the digits of
+// group x_h above h.  Every chain is one contiguous range of the pass's input.
+constexpr uint32_t MAXCH = 2 * NCH + 1;
+static_assert(!GS_HEAVY || MAXCH <= 64, "heavy-digit sub-chains need 2*NCH+1 <= 64 lanes");
+
+// per-pass info block (uint32 words), written by scan_kernel
+constexpr uint32_t I_START = 0;                // seg_start[MAXCH]
+constexpr uint32_t I_END = MAXCH;              // seg_end[MAXCH]
+constexpr uint32_t I_ROW = 2 * MAXCH;          // first descriptor row of each chain
+constexpr uint32_t PASS_FLAGS = 3 * MAXCH;     // PF_* bits
+constexpr uint32_t I_NCH = PASS_FLAGS + 1;     // chains in use (NCH or MAXCH)
+constexpr uint32_t I_CNT_H = PASS_FLAGS + 2;   // this pass gathers counts for the next one: heavy value of ITS digit (else ~0)
+constexpr uint32_t I_CNT_START = PASS_FLAGS + 3;   //   first output position of that value's run
+constexpr uint32_t I_CNT_SUBLEN = PASS_FLAGS + 4;  //   keys per position slice
+constexpr uint32_t I_XH = PASS_FLAGS + 5;          // heavy layout: digit group of the heavy value
+constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 6 + 31) / 32) * 32;
 constexpr uint32_t PF_SKEW = 1;    // some digit holds >= n/8 keys: rank with wave-aggregated adds
 constexpr uint32_t PF_SKIP = 2;     // every key has the same digit AND the pass is one of an even number of such
                                     // passes: the pass is the identity permutation, its workgroups exit at once
 constexpr uint32_t PF_SRC_ALT = 4;  // an odd number of earlier passes ran: this pass reads alt and writes keys
 constexpr uint32_t PF_LAST = 8;     // last pass that runs: applies the descending index reversal
+constexpr uint32_t PF_HEAVY = 16;   // heavy chain layout: tile 0 of chains 0..NCH-1 and 2*NCH seeds itself from HSUB
 
 // ---- state slab layout (uint32 words), shared by host and kernels -------------
 //  COUNTERS  tile tickets, [pass][chain]                       (reference m_index)
 //  STATUS    device status word
-//  INFO      per pass: seg_start[NCH+1], row_base[NCH+1]       (written by scan_kernel)
+//  INFO      per pass: the info block above                    (written by scan_kernel)
 //  HIST      joint histograms H[pass][chain][digit]            (reference m_globalHistogram)
+//  HSUB      per pass q: [NCH slices + 1][256] counts of digit q among the keys whose digit q-1 is the heavy
+//            value (by position slice of the pass's input) / lies below it inside its group
 //  DESC      descriptors: pass q at DESC + q*desc_stride, rows of 256 words
 constexpr uint32_t SLAB_COUNTERS = 0;
 constexpr uint32_t COUNTER_STRIDE = 32;  // one 128-byte line per ticket counter: chains do not share a line
-constexpr uint32_t SLAB_STATUS = 4 * 32 * COUNTER_STRIDE;  // 4 passes x <=32 chains
+constexpr uint32_t COUNTERS_PER_PASS = 72;  // >= MAXCH
+static_assert(COUNTERS_PER_PASS >= MAXCH, "ticket counters");
+constexpr uint32_t SLAB_STATUS = 4 * COUNTERS_PER_PASS * COUNTER_STRIDE;
 constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
-constexpr uint32_t INFO_STRIDE = 80;  // >= 2*(NCH+1)
 constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
-constexpr uint32_t SLAB_DESC = SLAB_HIST + 4 * NCH * RADIX;
+constexpr uint32_t SLAB_HSUB = SLAB_HIST + 4 * NCH * RADIX;
+constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
+constexpr uint32_t SLAB_DESC = SLAB_HSUB + 4 * HSUB_STRIDE;
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif
@@ -161,6 +195,11 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 
 template <int N>
 struct IntTag { static constexpr int value = N; };
+
+// tiles of a chain [s0, s1): its tile grid starts at s0 rounded down to 64 keys (256-byte aligned wave loads)
+__host__ __device__ __forceinline__ uint32_t chain_tiles(uint32_t s0, uint32_t s1, uint32_t tile_keys) {
+    return s1 != s0 ? (s1 - (s0 & ~63u) + tile_keys - 1u) / tile_keys : 0u;
+}
 
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
@@ -313,11 +352,14 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_t* desc, uint32_t* info,
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
                                                     uint32_t seg_len0, uint32_t tile_keys,
-                                                    uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip*/) {
+                                                    uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip
+                                                                    identity passes, bit2 (with bit1): heavy layout allowed*/) {
     __shared__ uint32_t s_wtot[2][4];
     __shared__ uint32_t s_cum[RADIX + 1];
-    __shared__ uint32_t s_rowbase[NCH + 1];
+    __shared__ uint32_t s_start[MAXCH], s_end[MAXCH], s_rowbase[MAXCH + 1];
     __shared__ uint32_t s_triv;
+    __shared__ unsigned long long s_best[2];  // heaviest value of [0] the previous digit (this pass's layout), [1] this digit
+    __shared__ uint32_t s_hv[2][2];           // its run start and count
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
@@ -343,7 +385,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
 #pragma unroll
         for (uint32_t x = 0; x < NCH; ++x) hq[x] = q == 0 ? h[0][x] : q == 1 ? h[1][x] : q == 2 ? h[2][x] : h[3][x];
     }
-    if (tid == 0) s_triv = 0;
+    if (tid == 0) { s_triv = 0; s_best[0] = 0; s_best[1] = 0; }
     __syncthreads();
 
     // ---- which passes run (full sorts only).  A pass whose digit is the same for every key is the identity
@@ -355,6 +397,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         for (uint32_t qq = 0; qq < 4; ++qq)
             if (g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
     }
+    // ---- heavy values (full sorts of >= GS_HEAVY_MIN_KEYS keys): a digit count above n / GS_HEAVY_SHARE (the
+    // largest, ties to the smaller digit).  Workgroup q decides the layout of pass q from digit q-1 and what pass q must count
+    // for pass q+1 from digit q; workgroup q+1 reads the same totals, so both sides agree.
+    const bool heavy_on = GS_HEAVY && (plan & 4u) && n >= GS_HEAVY_MIN_KEYS;
+    if (heavy_on) {
+        if (q >= 1 && gprev > n / GS_HEAVY_SHARE) atomicMax(&s_best[0], ((unsigned long long)gprev << 8) | (255u - tid));
+        if (q < 3 && g > n / GS_HEAVY_SHARE) atomicMax(&s_best[1], ((unsigned long long)g << 8) | (255u - tid));
+    }
     // digit scans of this pass's totals and (for the segment starts) of the previous digit's totals
     const uint32_t incl = wave_inclusive_scan(g, lane);
     const uint32_t incl_prev = wave_inclusive_scan(gprev, lane);
@@ -362,18 +412,29 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     __syncthreads();
     uint32_t base = 0, base_prev = 0;
     for (uint32_t w = 0; w < wave; ++w) { base += s_wtot[0][w]; base_prev += s_wtot[1][w]; }
-    if ((plan & 2u) && tid == 0) {
+    uint32_t skip = 0;  // uniform: passes that are dropped
+    if (plan & 2u) {
         const uint32_t triv = s_triv;
         uint32_t drop = (uint32_t)__popc(triv) & ~1u;
         if ((plan & 1u) && drop == 4u) drop = 2u;
-        uint32_t skip = 0;
         for (uint32_t qq = 0; qq < 4 && drop; ++qq)
             if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
+    }
+    uint32_t h_use = 0xffffffffu, h_cnt = 0xffffffffu;  // uniform
+    if (heavy_on) {
+        // the slices of pass q are counted by pass q-1 while it writes them: both passes must run
+        if (!(GS_EXP & 64) && q >= 1 && s_best[0] != 0 && ((skip >> (q - 1)) & 3u) == 0u) h_use = 255u - (uint32_t)(s_best[0] & 255u);
+        if (q < 3 && s_best[1] != 0 && ((skip >> q) & 3u) == 0u) h_cnt = 255u - (uint32_t)(s_best[1] & 255u);
+    }
+    if (tid == h_use) { s_hv[0][0] = base_prev + incl_prev - gprev; s_hv[0][1] = gprev; }
+    if (tid == h_cnt) { s_hv[1][0] = base + incl - g; s_hv[1][1] = g; }
+    if ((plan & 2u) && tid == 0) {
         const uint32_t run = ~skip & 15u;
         uint32_t f = 0;
         if ((skip >> q) & 1u) f |= PF_SKIP;
         if (__popc(run & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
         if (run && q == 31u - (uint32_t)__clz(run)) f |= PF_LAST;
+        if (h_use != 0xffffffffu) f |= PF_HEAVY;
         if (f) atomicOr(&my_info[PASS_FLAGS], f);
     }
 
@@ -393,31 +454,65 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         if (tid <= NCH) s_cum[tid] = v;  // compact: s_cum[x] = start of digit group x
     }
     __syncthreads();
+    // chains (see MAXCH): every chain one contiguous range [start, end) of this pass's input
+    auto slice_len = [](uint32_t count) { return ((count + NCH - 1) / NCH + 63u) & ~63u; };
+    if (tid < MAXCH) {
+        uint32_t st = 0, en = 0;
+        if (h_use == 0xffffffffu) {
+            if (tid < NCH) { st = s_cum[tid]; en = s_cum[tid + 1]; }
+        } else {
+            const uint32_t hs = s_hv[0][0], he = hs + s_hv[0][1], sl = slice_len(s_hv[0][1]);
+            const uint32_t xh = h_use / (RADIX / NCH);
+            if (tid < NCH) {  // slices of the heavy value's run
+                const uint32_t a = hs + tid * sl;
+                st = a < he ? a : he;
+                en = a + sl < he ? a + sl : he;
+            } else if (tid < 2 * NCH) {  // digit groups; the heavy value's group keeps the digits below it
+                const uint32_t x = tid - NCH;
+                st = s_cum[x];
+                en = x == xh ? hs : s_cum[x + 1];
+            } else {  // the digits above the heavy value inside its group
+                st = he;
+                en = s_cum[xh + 1];
+            }
+        }
+        s_start[tid] = st;
+        s_end[tid] = en;
+    }
+    __syncthreads();
     // first descriptor row of every chain: a wave-level scan over the chains' row counts
     if (wave == 0) {
         uint32_t rows = 0;
-        if (lane < NCH) {
-            const uint32_t a = s_cum[lane] & ~63u;  // the chain's tile grid starts on a 256-byte boundary
-            rows = (s_cum[lane + 1] - a + tile_keys - 1) / tile_keys + 1u;
-        }
+        if (lane < MAXCH) rows = chain_tiles(s_start[lane], s_end[lane], tile_keys) + 1u;
         const uint32_t rincl = wave_inclusive_scan(rows, lane);
-        if (lane <= NCH) s_rowbase[lane] = rincl - rows;  // lane NCH: rows == 0 -> the total
+        if (lane <= MAXCH) s_rowbase[lane] = rincl - rows;
     }
     __syncthreads();
-    if (tid <= NCH) {
-        my_info[tid] = s_cum[tid];
-        my_info[NCH + 1 + tid] = s_rowbase[tid];
+    if (tid < MAXCH) {
+        my_info[I_START + tid] = s_start[tid];
+        my_info[I_END + tid] = s_end[tid];
+        my_info[I_ROW + tid] = s_rowbase[tid];
+    }
+    if (tid == 0) {
+        my_info[I_NCH] = h_use == 0xffffffffu ? NCH : MAXCH;
+        my_info[I_XH] = h_use == 0xffffffffu ? 0u : h_use / (RADIX / NCH);
+        my_info[I_CNT_H] = h_cnt;
+        my_info[I_CNT_START] = h_cnt == 0xffffffffu ? 0u : s_hv[1][0];
+        my_info[I_CNT_SUBLEN] = h_cnt == 0xffffffffu ? 1u : slice_len(s_hv[1][1]);
     }
 
     // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
     // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
     const unsigned long long heavy = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
     if (lane == 0 && heavy) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
-    // digit starts and chain bases
+    // digit starts and chain bases.  Heavy layout: the group chains (NCH + x) are seeded here; the slices and
+    // the upper part of the heavy group depend on counts gathered by the previous pass — tile 0 of each of
+    // those chains seeds its own row 0 when it starts (digit_binning_kernel).
     uint32_t run = base + incl - g;  // dstart[tid]
+    const uint32_t first = h_use == 0xffffffffu ? 0u : NCH;
 #pragma unroll
     for (uint32_t x = 0; x < NCH; ++x) {
-        my_desc[(size_t)s_rowbase[x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
+        my_desc[(size_t)s_rowbase[first + x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
         run += hq[x];
     }
 }
@@ -440,7 +535,7 @@ struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
     static constexpr int STAGE_BYTES = TILE * (VB == 8 ? 8 : 4);
-    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64;
+    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + 2 * RADIX * 4;
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
     // look-back wait is covered by its neighbours' work
@@ -460,8 +555,9 @@ template <int THREADS, int KPT, int VB, int KT, int RANK>
 __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)) void digit_binning_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b,  // the pass reads a and writes b, unless ...
     uint32_t* desc,          // this pass: rows of 256 descriptor words; chain x starts at row_base[x]
-    uint32_t* counters,      // this pass: NCH ticket counters
-    const uint32_t* info,    // this pass: seg_start[NCH+1], row_base[NCH+1], flags
+    uint32_t* counters,      // this pass: one ticket counter per chain
+    const uint32_t* info,    // this pass: the info block written by scan_kernel
+    uint32_t* hsub,          // SLAB_HSUB: read [pass] (heavy layout), added to [pass + 1] (counting pass)
     uint32_t* status, uint32_t n, uint32_t shift,
     uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
@@ -478,11 +574,15 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_raw + Cfg::STAGE_BYTES);
     uint32_t* s_dpre = s_whist + WAVES * RADIX;  // tile-local exclusive digit prefix
     uint32_t* s_gbase = s_dpre + RADIX;          // global base of digit run minus s_dpre
-    uint32_t* s_misc = s_gbase + RADIX;          // [0] chain, [1] ticket (~0 = none), [4..7] wave totals of the digit scan
+    uint32_t* s_misc = s_gbase + RADIX;          // [0] chain, [1] ticket (~0 = none), [4..7] wave totals of the digit scan,
+                                                 // [9..14] the pass's flag/plan words
 
+    uint32_t* s_tcnt = s_misc + 16;              // counting pass: next-digit counts of the tile's heavy-value keys [0, 256)
+                                                 // and of the keys below it in its digit group [256, 512)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+    for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
 #if (GS_EXP & 2)
     uint32_t* trace = reinterpret_cast<uint32_t*>(((unsigned long long)status[9] << 32) | status[8]) +
                       ((size_t)(shift >> 3) * gridDim.x + blockIdx.x) * 8;
@@ -501,9 +601,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     // An earlier pass of this sort gave up (status word set): its output is incomplete, so positions derived
     // from the upfront histograms no longer bound this pass's writes — do nothing.  Read by another wave, in
-    // flight together with the ticket atomic, so it adds no latency.  Same for the pass's flag word.
+    // flight together with the ticket atomic, so it adds no latency.  Same for the pass's flag and plan words.
     if (tid == 64) s_misc[3] = ld_agent(status);
-    if (tid == 128) s_misc[9] = info[PASS_FLAGS];
+    if (tid >= 128 && tid < 134) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, cnt_h, cnt_start, cnt_sublen, xh
     __syncthreads();
     if (s_misc[3] != STATUS_OK) return;
     const uint32_t pflags = s_misc[9];
@@ -514,20 +614,22 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const void* vals_in_ = swapped ? vals_b : vals_a;
     void* vals_out_ = swapped ? vals_a : vals_b;
     const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
+    const uint32_t nch = s_misc[10];                                      // chains of this pass (NCH or MAXCH)
+    const uint32_t cnt_h = (mode & 2u) ? s_misc[11] : 0xffffffffu;        // heavy value this pass counts for the next one
+    const uint32_t cnt_start = s_misc[12], cnt_sublen = s_misc[13];
     uint32_t tile = s_misc[1];
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
-    uint32_t seg_start = info[chain], seg_end = info[chain + 1];
-    if (tile >= (seg_end - (seg_start & ~63u) + TILE - 1) / TILE) {  // uniform
+    uint32_t seg_start = info[I_START + chain], seg_end = info[I_END + chain];
+    if (tile >= chain_tiles(seg_start, seg_end, TILE)) {  // uniform
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
         __syncthreads();
         if (wave == 0) {
             uint32_t tiles_x = 0;
             bool open = false;
-            if (lane < NCH) {
-                const uint32_t s0 = info[lane], s1 = info[lane + 1];
-                tiles_x = s1 != s0 ? (s1 - (s0 & ~63u) + TILE - 1) / TILE : 0u;
+            if (lane < nch) {
+                tiles_x = chain_tiles(info[I_START + lane], info[I_END + lane], TILE);
                 open = ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(open);
@@ -540,7 +642,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 const uint32_t incl = wave_inclusive_scan(tiles_x, lane);
                 const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
                 const uint32_t v = (uint32_t)(((unsigned long long)(blockIdx.x * 0x9E3779B1u) * total) >> 32);
-                const unsigned long long ge = __builtin_amdgcn_ballot_w64(lane < NCH && incl > v);
+                const unsigned long long ge = __builtin_amdgcn_ballot_w64(lane < nch && incl > v);
                 const uint32_t x = ge ? (uint32_t)__builtin_ctzll(ge) : 0u;
                 if ((m >> x) & 1ull) {
                     uint32_t t = 0;
@@ -551,8 +653,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 }
             }
             while (m) {  // wave-uniform: try the open chains one by one, starting after our own
-                const unsigned long long rot = (m >> chain) | (m << ((NCH - chain) & 63));
-                const uint32_t x = (chain + (uint32_t)__builtin_ctzll(rot & ((1ull << NCH) - 1ull))) & (NCH - 1);
+                const unsigned long long above = m & ~((2ull << chain) - 1ull);  // chain < NCH <= 32
+                const uint32_t x = (uint32_t)__builtin_ctzll(above ? above : m);
                 uint32_t t = 0;
                 if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
                 t = __builtin_amdgcn_readfirstlane(t);
@@ -566,8 +668,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         chain = s_misc[0];
         tile = s_misc[1];
         if (tile == 0xffffffffu) return;  // every chain is fully claimed
-        seg_start = info[chain];
-        seg_end = info[chain + 1];
+        seg_start = info[I_START + chain];
+        seg_end = info[I_END + chain];
     }
     const uint32_t tile_base = (seg_start & ~63u) + tile * TILE;
     const uint32_t lo = tile_base > seg_start ? tile_base : seg_start;  // valid keys: [lo, hi)
@@ -575,7 +677,20 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t count = hi - lo;
     const uint32_t head = lo - tile_base;  // masked keys in front (first tile of a chain only)
     const bool full = (count == TILE);
-    uint32_t* cdesc = desc + (size_t)info[NCH + 1 + chain] * RADIX;  // row 0 of this chain
+    uint32_t* cdesc = desc + (size_t)info[I_ROW + chain] * RADIX;  // row 0 of this chain
+    // Heavy layout: the slices of the heavy value's run (chains < NCH) and the digits above it (chain 2*NCH)
+    // start where the counts gathered by the PREVIOUS pass say — tile 0 of such a chain seeds its row 0 now,
+    // long before a successor can walk that far: seed of the heavy group's chain (set by scan_kernel)
+    // + keys of that group below the heavy value + the slices in front of this one.
+    if ((pflags & PF_HEAVY) && tile == 0u && (chain < NCH || chain == 2 * NCH) && tid < RADIX) {
+        const uint32_t* hs = hsub + (shift >> 3) * HSUB_STRIDE;
+        const uint32_t grp_chain = NCH + s_misc[14];
+        uint32_t seed = ld_agent(&desc[(size_t)info[I_ROW + grp_chain] * RADIX + tid]) >> 2;
+        seed += hs[NCH * RADIX + tid];
+        const uint32_t in_front = chain < NCH ? chain : NCH;
+        for (uint32_t s = 0; s < in_front; ++s) seed += hs[s * RADIX + tid];
+        st_agent(&cdesc[tid], (seed << 2) | FLAG_INCLUSIVE);
+    }
     GS_TRACE(1);
 
     // ---- load (wave-striped, coalesced 256 B per wave-instruction) ----
@@ -703,6 +818,30 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                     if (i & 1) offp[i >> 1] |= r << 16; else offp[i >> 1] |= r;
                 }
             }
+            // Counting pass (a heavy value implies a skewed pass): next-digit counts of the tile's heavy-value
+            // keys.  A loop of its own — inside the ranking loop its non-returning adds made the compiler wait
+            // for every ranking atomic (+0.17 ms per pass).  Every thread keeps the count of its own most
+            // frequent next digit (the first it meets) in a register; only the other keys cost an LDS add.
+            if (cnt_h != 0xffffffffu && !(GS_EXP & 16)) {  // uniform
+                uint32_t cnt_mine = 0xffffffffu, cnt_l0 = 0;
+                const uint32_t grp_lo = cnt_h & ~(RADIX / NCH - 1u);
+                // straight-line selects and ONE predicated add per key (the branchy form cost 45 instructions
+                // and 8 scalar branches per key: +0.17 ms per pass)
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t d = (key[i] >> shift) & 255u;
+                    const uint32_t dn = (key[i] >> (shift + 8u)) & 255u;
+                    const uint32_t idx = my_base + i * 64u;
+                    const bool valid = full || (idx >= lo && idx < hi);
+                    const bool is_h = valid && d == cnt_h;
+                    const bool is_a = valid && d < cnt_h && d >= grp_lo;
+                    const bool match = is_h && (dn == cnt_mine || cnt_mine == 0xffffffffu);
+                    cnt_mine = match ? dn : cnt_mine;
+                    cnt_l0 += match ? 1u : 0u;
+                    if ((is_h && !match) || is_a) atomicAdd(&s_tcnt[(is_a ? RADIX : 0u) + dn], 1u);
+                }
+                if (cnt_l0) atomicAdd(&s_tcnt[cnt_mine], cnt_l0);
+            }
         }
     }
     GS_TRACE(2);
@@ -792,7 +931,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if (stalled) {
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
-                if (GS_FALLBACK && spins > FALLBACK_SPINS) {
+                if (GS_FALLBACK && k > 0 && spins > FALLBACK_SPINS) {  // (row 0 of a heavy-layout chain is seeded by its tile 0)
                     atomicMax(&s_misc[8], (uint32_t)k);  // ask the workgroup to recount tile k-1
                     return;
                 }
@@ -877,6 +1016,34 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
     }
 
+    // ---- counting pass (heavy value cnt_h of THIS digit): the next pass splits the value's run into NCH
+    // position slices and needs, per slice, the counts of its own digit.  The tile's totals were gathered
+    // while ranking (s_tcnt); now that the run's output position is known they go to the slice it falls
+    // into.  A tile's run is at most one tile long and a slice is at least one, so the run touches at most
+    // two slices — the few tiles per pass whose run crosses a slice boundary recount it by position.
+    uint32_t* s_cnt = s_whist + RADIX;  // recount: 2 x 256 words; the per-wave counters are dead, [0, 256) is the fallback's
+    uint32_t cnt_first = 0;
+    bool cnt_split = false;
+    if (cnt_h != 0xffffffffu) {  // uniform
+        const uint32_t o_first = s_gbase[cnt_h] + s_dpre[cnt_h] + (cnt_h == 0u ? head : 0u);
+        const uint32_t run_end = s_gbase[cnt_h] + (cnt_h == 255u ? head + count : s_dpre[cnt_h + 1u]);  // one past the run's last key
+        cnt_first = (o_first - cnt_start) / cnt_sublen;
+        const uint32_t boundary = cnt_start + (cnt_first + 1u) * cnt_sublen;
+        cnt_split = run_end > boundary;
+        if (cnt_split) {
+            for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_cnt[i] = 0;
+            __syncthreads();
+            const uint32_t gb_h = s_gbase[cnt_h];
+#pragma unroll 4
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t i = tid + j * THREADS;
+                const uint32_t kb = s_stage[i];
+                if ((full || (i >= head && i < head + count)) && ((kb >> shift) & 255u) == cnt_h)
+                    atomicAdd(&s_cnt[(gb_h + i >= boundary ? RADIX : 0u) + ((kb >> (shift + 8u)) & 255u)], 1u);
+            }
+        }
+    }
+
     // ---- scatter runs to global memory (slot i of the stage -> s_gbase[digit] + i) ----
     uint32_t digs[VB != 0 ? KPT / 4 : 1];  // digit of stage slot tid + j*THREADS, 4 per register (value phase)
     if constexpr (VB != 0) {
@@ -911,6 +1078,23 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if (reverse) o = n - 1u - o;
             if (GS_EXP & 1) o = (tile_base + i) % n;
             if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
+        }
+    }
+    if (cnt_h != 0xffffffffu && !(GS_EXP & 32)) {  // hand the tile's counts to the next pass
+        uint32_t* hs = hsub + ((shift >> 3) + 1u) * HSUB_STRIDE;
+        if (cnt_split) __syncthreads();  // the recount is complete
+        for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) {
+            if (i >= RADIX) {  // keys of the heavy value's digit group below it
+                const uint32_t v = s_tcnt[i];
+                if (v != 0u) atomicAdd(&hs[NCH * RADIX + (i - RADIX)], v);
+            } else if (!cnt_split) {
+                const uint32_t v = s_tcnt[i];
+                if (v != 0u && cnt_first < NCH) atomicAdd(&hs[cnt_first * RADIX + i], v);
+            } else {
+                const uint32_t v0 = s_cnt[i], v1 = s_cnt[RADIX + i];
+                if (v0 != 0u && cnt_first < NCH) atomicAdd(&hs[cnt_first * RADIX + i], v0);
+                if (v1 != 0u && cnt_first + 1u < NCH) atomicAdd(&hs[(cnt_first + 1u) * RADIX + i], v1);
+            }
         }
     }
 }

@@ -474,3 +474,36 @@ def test_dropped_passes_cost_nothing(gpu):
     real = min(best["pass0"], best["pass1"])
     assert max(best["pass2"], best["pass3"]) < 0.5 * real, best
     s.close()
+
+
+def _heavy_inputs(oracle, n):
+    rng = np.random.default_rng(99)
+    u = oracle.init_random(n, 777, 0)
+    yield "and-skew p=1/8", oracle.init_random(n, 31, 2)
+    yield "and-skew p=1/32", oracle.init_random(n, 33, 4)
+    # every byte is 0x35 with probability 1/2, else uniform: the heavy value sits in the middle of its digit
+    # group, with neighbours below and above it in every pass
+    k = u.copy()
+    for b in range(4):
+        pick = rng.random(n) < 0.5
+        k = np.where(pick, (k & np.uint32(~(0xFF << (8 * b)) & 0xFFFFFFFF)) | np.uint32(0x35 << (8 * b)), k)
+    yield "0x35 half of every byte", k.astype(np.uint32)
+    yield "constant middle byte", ((u & np.uint32(0xFF00FFFF)) | np.uint32(0x00C30000)).astype(np.uint32)
+    yield "90% one key", np.where(rng.random(n) < 0.9, np.uint32(0x80402010), u).astype(np.uint32)
+    yield "heavy value 255", (u | np.where(rng.random(n) < 0.6, np.uint32(0x0000FF00), np.uint32(0))).astype(np.uint32)
+
+
+@pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (4, 0, 0), (8, 0, 1), (0, 1, 1), (4, 2, 0)])
+def test_heavy_value_position_slices(gpu, oracle, vb, kt, order):
+    """A digit value holding > 1/4 of the keys: the next pass splits its run into position slices whose
+    bases come from counts gathered by the pass before (n >= 2^22 switches that layout on)."""
+    n = (1 << 22) + 54321
+    for name, keys in _heavy_inputs(oracle, n):
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ok, ov = _gpu_sort(gpu, keys, kt, order, vals)
+        if vals is None:
+            np.testing.assert_array_equal(ok, oracle.std_sort(keys, kt, order), err_msg=name)
+        else:
+            rk, rv = oracle.std_sort(keys, kt, order, vals)
+            np.testing.assert_array_equal(ok, rk, err_msg=name)
+            np.testing.assert_array_equal(ov, rv, err_msg=name)
