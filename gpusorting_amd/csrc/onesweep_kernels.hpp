@@ -70,8 +70,10 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 // (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
 //  returns a not-yet-final row and the wait moves in front of staging)
 #ifndef GS_ADAPTIVE_BATCH
-#define GS_ADAPTIVE_BATCH 1  // a chain holding a large share of the pass's tiles (skewed digit groups) fetches 4 or 16
-                             // rows per look-back round trip: walk length ~ (tile rate of the chain) / batch
+#define GS_ADAPTIVE_BATCH 0  // 1 = a chain holding a large share of the pass's tiles (skewed digit groups) fetches 4 or
+                             // 16 rows per look-back round trip.  Measured: -3 % on the worst presets (the wait in a
+                             // crowded chain is for predecessors to publish at all, not for the walk), while the two
+                             // extra unrolled walks cost the uniform case 1-2 % in code size alone.  Off.
 #endif
 #ifndef GS_NB_HEAVY
 #define GS_NB_HEAVY 16u  // rows per round trip in a chain that holds at least half of the pass's tiles (64 measured
@@ -195,6 +197,10 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 
 template <int N>
 struct IntTag { static constexpr int value = N; };
+// block placement: the rare paths (steal, partial tiles, skew, fallback, heavy-value bookkeeping) tripled the
+// kernel's code; keeping the common path contiguous keeps it in the instruction cache
+#define GS_LIKELY(x) __builtin_expect(!!(x), 1)
+#define GS_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 // tiles of a chain [s0, s1): its tile grid starts at s0 rounded down to 64 keys (256-byte aligned wave loads)
 __host__ __device__ __forceinline__ uint32_t chain_tiles(uint32_t s0, uint32_t s1, uint32_t tile_keys) {
@@ -535,7 +541,9 @@ struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
     static constexpr int STAGE_BYTES = TILE * (VB == 8 ? 8 : 4);
-    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + 2 * RADIX * 4;
+    // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
+    static constexpr bool HEAVY = GS_HEAVY && VB == 0;
+    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
     // look-back wait is covered by its neighbours' work
@@ -582,7 +590,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
-    for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
+    if constexpr (Cfg::HEAVY)
+        for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
 #if (GS_EXP & 2)
     uint32_t* trace = reinterpret_cast<uint32_t*>(((unsigned long long)status[9] << 32) | status[8]) +
                       ((size_t)(shift >> 3) * gridDim.x + blockIdx.x) * 8;
@@ -608,20 +617,24 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     if (s_misc[3] != STATUS_OK) return;
     const uint32_t pflags = s_misc[9];
     if ((mode & 2u) && (pflags & PF_SKIP)) return;  // identity pass of a full sort
+#ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with GPUSORT_SKIP_PASSES=0)
+    const bool swapped = false;
+#else
     const bool swapped = (mode & 2u) && (pflags & PF_SRC_ALT);
+#endif
     const uint32_t* keys_in = swapped ? keys_b : keys_a;
     uint32_t* keys_out = swapped ? keys_a : keys_b;
     const void* vals_in_ = swapped ? vals_b : vals_a;
     void* vals_out_ = swapped ? vals_a : vals_b;
     const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
     const uint32_t nch = s_misc[10];                                      // chains of this pass (NCH or MAXCH)
-    const uint32_t cnt_h = (mode & 2u) ? s_misc[11] : 0xffffffffu;        // heavy value this pass counts for the next one
+    const uint32_t cnt_h = (Cfg::HEAVY && (mode & 2u)) ? s_misc[11] : 0xffffffffu;  // heavy value this pass counts for the next one
     const uint32_t cnt_start = s_misc[12], cnt_sublen = s_misc[13];
     uint32_t tile = s_misc[1];
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
     uint32_t seg_start = info[I_START + chain], seg_end = info[I_END + chain];
-    if (tile >= chain_tiles(seg_start, seg_end, TILE)) {  // uniform
+    if (GS_UNLIKELY(tile >= chain_tiles(seg_start, seg_end, TILE))) {  // uniform
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
         __syncthreads();
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // start where the counts gathered by the PREVIOUS pass say — tile 0 of such a chain seeds its row 0 now,
     // long before a successor can walk that far: seed of the heavy group's chain (set by scan_kernel)
     // + keys of that group below the heavy value + the slices in front of this one.
-    if ((pflags & PF_HEAVY) && tile == 0u && (chain < NCH || chain == 2 * NCH) && tid < RADIX) {
+    if (GS_UNLIKELY(Cfg::HEAVY && (pflags & PF_HEAVY) && tile == 0u && (chain < NCH || chain == 2 * NCH) && tid < RADIX)) {
         const uint32_t* hs = hsub + (shift >> 3) * HSUB_STRIDE;
         const uint32_t grp_chain = NCH + s_misc[14];
         uint32_t seed = ld_agent(&desc[(size_t)info[I_ROW + grp_chain] * RADIX + tid]) >> 2;
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // ---- load (wave-striped, coalesced 256 B per wave-instruction) ----
     uint32_t key[KPT];
     const uint32_t my_base = tile_base + wave * (64u * KPT) + lane;
-    if (full) {
+    if (GS_LIKELY(full)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(ld_stream<VB == 0>(keys_in + my_base + i * 64u));
     } else {
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         // where the LDS hands same-address lanes of ONE wave-instruction their
         // results in ascending lane order; gs_selftest_lds_atomic_order() probes
         // exactly that on the device before this path is ever selected.
-        if ((pflags & PF_SKEW) == 0u && full) {  // uniform per pass (set by scan_kernel)
+        if (GS_LIKELY((pflags & PF_SKEW) == 0u && full)) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
@@ -878,14 +891,27 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // ---- stage keys in LDS, sorted by digit (stable) ----
     // mask_tail: the tile's trailing dummies were not ranked (above) and are not staged
     const bool mask_tail = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
+    if (GS_LIKELY(!mask_tail)) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t d = (key[i] >> shift) & 255u;
-        const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
-        if (!mask_tail || my_base + i * 64u < hi) s_stage[lpos] = key[i];
-        if constexpr (VB != 0) {  // values follow the same positions later
-            if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
-            else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = (key[i] >> shift) & 255u;
+            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
+            s_stage[lpos] = key[i];
+            if constexpr (VB != 0) {  // values follow the same positions later
+                if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
+                else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = (key[i] >> shift) & 255u;
+            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
+            if (my_base + i * 64u < hi) s_stage[lpos] = key[i];
+            if constexpr (VB != 0) {
+                if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
+                else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+            }
         }
     }
 
@@ -945,10 +971,13 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     GS_TRACE(4);
     for (;;) {
         if (!finished) {
-            if (nb == 64u) walk(IntTag<64>{});
-            else if (nb == 16u) walk(IntTag<16>{});
+#if GS_ADAPTIVE_BATCH
+            if (GS_LIKELY(nb == 1u)) walk(IntTag<1>{});
             else if (nb == 4u) walk(IntTag<4>{});
-            else walk(IntTag<1>{});
+            else walk(IntTag<16>{});
+#else
+            walk(IntTag<1>{});
+#endif
             if (done) {
                 finished = true;
                 if (poisoned) {
@@ -964,7 +993,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         __syncthreads();
         if (!GS_FALLBACK) break;
         const uint32_t fb_row = s_misc[8];  // uniform
-        if (fb_row == 0u) break;
+        if (GS_LIKELY(fb_row == 0u)) break;
         // ---- fallback: some digit's walk waited FALLBACK_SPINS polls on row fb_row.  The whole workgroup
         // recounts that tile's digits from the pass input (which nobody writes during the pass), offers the
         // counts to everyone as REDUCTION descriptors (compare-and-swap on NOT_READY: whatever the owner
@@ -1004,7 +1033,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     V val[VB != 0 ? KPT : 1];
     if constexpr (VB != 0) {
         const V* vals_in = reinterpret_cast<const V*>(vals_in_);
-        if (full) {
+        if (GS_LIKELY(full)) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
         } else {  // clamped, unconditional (see the key loads); slots outside [lo, hi) are never written out
@@ -1024,7 +1053,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     uint32_t* s_cnt = s_whist + RADIX;  // recount: 2 x 256 words; the per-wave counters are dead, [0, 256) is the fallback's
     uint32_t cnt_first = 0;
     bool cnt_split = false;
-    if (cnt_h != 0xffffffffu) {  // uniform
+    if (GS_UNLIKELY(cnt_h != 0xffffffffu)) {  // uniform
         const uint32_t o_first = s_gbase[cnt_h] + s_dpre[cnt_h] + (cnt_h == 0u ? head : 0u);
         const uint32_t run_end = s_gbase[cnt_h] + (cnt_h == 255u ? head + count : s_dpre[cnt_h + 1u]);  // one past the run's last key
         cnt_first = (o_first - cnt_start) / cnt_sublen;
@@ -1067,9 +1096,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         V* vals_out = reinterpret_cast<V*>(vals_out_);
         V* s_vstage = reinterpret_cast<V*>(s_raw);
         __syncthreads();  // everyone is done reading the key stage
+        if (GS_LIKELY(!mask_tail)) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            if (!mask_tail || my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
+            for (int i = 0; i < KPT; ++i) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                if (my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
@@ -1080,7 +1114,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
         }
     }
-    if (cnt_h != 0xffffffffu && !(GS_EXP & 32)) {  // hand the tile's counts to the next pass
+    if (GS_UNLIKELY(cnt_h != 0xffffffffu && !(GS_EXP & 32))) {  // hand the tile's counts to the next pass
         uint32_t* hs = hsub + ((shift >> 3) + 1u) * HSUB_STRIDE;
         if (cnt_split) __syncthreads();  // the recount is complete
         for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) {

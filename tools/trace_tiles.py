@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-tile phase timing of the DigitBinningPass (needs the GS_EXP=2 build:
-GPUSORT_LIB=gpusorting_amd/lib/libgpusort_trace.so).  Usage: trace_tiles.py [log2=28] [TxK=512x32] [entropy_preset_index=0]"""
+GPUSORT_LIB=gpusorting_amd/lib/libgpusort_trace.so).  Usage: trace_tiles.py [log2=28] [TxK=512x32] [entropy_preset_index=0] [value_bytes=0]"""
 import ctypes as C
 import os
 import sys
@@ -18,20 +18,22 @@ def main():
     log2 = int(a[0]) if a else 28
     t, k = (int(x) for x in (a[1] if len(a) > 1 else "512x32").split("x"))
     preset = int(a[2]) if len(a) > 2 else 0
+    vb = int(a[3]) if len(a) > 3 else 0
     n = 1 << log2
     lib = _lib.load()
     lib.gs_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
     keys = torch.empty(n, dtype=torch.int32, device="cuda")
     alt = torch.empty_like(keys)
-    s = g.OneSweep(n)
+    s = g.OneSweep(n, mode=g.MODE_PAIRS if vb else g.MODE_KEYS_ONLY, value_bytes=vb)
+    vals = None if not vb else torch.empty(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
     s.set_shape(t, k)
     grid = (n + t * k - 1) // (t * k) + 16
     tr = torch.zeros(4 * grid * 8, dtype=torch.int32, device="cuda")
     lib.gs_debug_set_trace(s._h, tr.data_ptr())
     for rep in range(2):
-        g.init_random(keys, 10 + rep, preset)
+        g.init_random(keys, 10 + rep, preset, vals)
         torch.cuda.synchronize()
-        s.sort(keys, alt_keys=alt)
+        s.sort(keys, vals)
         s.check()
     d = tr.cpu().numpy().view(np.uint32).reshape(4, grid, 8).astype(np.int64)
     names = ["claim", "load+rank", "reduce+RED+fold", "stage", "lookback", "scatter", "tile total"]
