@@ -13,7 +13,8 @@ def main():
         print("-- kernel stats (top_kernels): name | calls | total_ms | avg_us | %")
         for name, calls, total, avg, pct in cur.execute(
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
-            print(f"{name[:110]:110s} | {calls:5d} | {total/1e6:10.3f} | {avg/1e3:10.2f} | {pct:6.2f}")
+            # the top_kernels view reports microseconds
+            print(f"{name[:110]:110s} | {calls:5d} | {total/1e3:10.3f} | {avg:10.2f} | {pct:6.2f}")
         try:
             cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
             rows = list(cur.execute("select * from counters_collection"))
