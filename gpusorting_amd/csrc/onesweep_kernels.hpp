@@ -969,6 +969,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
     };
     GS_TRACE(4);
+#if (GS_EXP & 256)  // ablation: no look-back wait, but the real scatter pattern — every earlier tile of the chain is
+                    // assumed to hold the same digit counts as this one (positions approximate, wrapped into range)
+    if (!finished) { prev = (ld_agent(&cdesc[tid]) >> 2) + tile * tile_total; done = true; }
+#endif
     for (;;) {
         if (!finished) {
 #if GS_ADAPTIVE_BATCH
@@ -1087,6 +1091,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         uint32_t o = s_gbase[d] + i;
         if (reverse) o = n - 1u - o;
         if (GS_EXP & 1) o = (tile_base + i) % n;  // ablation: positions are meaningless without the look-back
+        if (GS_EXP & 256) o = o % n;
         if (full || (i >= head && i < head + count)) st_stream(keys_out + o, from_bits<KT>(kb));
         if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
     }

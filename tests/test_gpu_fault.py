@@ -34,9 +34,11 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
         import sys, time, torch
         sys.path.insert(0, %r)
         import gpusorting_amd as g
-        for n, pairs in ((1 << 22, False), ((1 << 22) + 12345, True)):   # tile 5 of chain 3 stays silent in every pass
+        # tile 5 of chain 3 stays silent in every pass; the third case is skewed enough (entropy preset 5) for the
+        # heavy-value layout, where chain 3 is a position slice whose row 0 its tile 0 seeds itself
+        for n, pairs, preset in ((1 << 22, False, 0), ((1 << 22) + 12345, True, 0), ((1 << 23) + 777, False, 4)):
             k = torch.empty(n, dtype=torch.int32, device="cuda")
-            g.init_random(k, 10, 0)
+            g.init_random(k, 10, preset)
             v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
             ref = torch.sort(k.to(torch.int64) & 0xffffffff, stable=True)
             s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
@@ -48,7 +50,7 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
                 ok = ok and bool((v.to(torch.int64) == ref.indices).all().item())
             print("RESULT", "exact" if ok else "WRONG", "seconds", round(time.time() - t0, 3))
     """)
-    assert out.count("RESULT exact") == 2, out
+    assert out.count("RESULT exact") == 3, out
     assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
 
 
