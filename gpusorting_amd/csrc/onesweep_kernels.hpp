@@ -1084,17 +1084,31 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int j = 0; j < KPT / 4; ++j) digs[j] = 0;
     }
+    if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+        // the common case as straight-line code: all stage reads first, then the base look-ups, then the stores
+        // (with the masks and the reversal in the loop every key got its own branches and LDS round trips)
+        uint32_t kb[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const uint32_t i = tid + j * THREADS;
-        const uint32_t kb = s_stage[i];
-        const uint32_t d = (kb >> shift) & 255u;
-        uint32_t o = s_gbase[d] + i;
-        if (reverse) o = n - 1u - o;
-        if (GS_EXP & 1) o = (tile_base + i) % n;  // ablation: positions are meaningless without the look-back
-        if (GS_EXP & 256) o = o % n;
-        if (full || (i >= head && i < head + count)) st_stream(keys_out + o, from_bits<KT>(kb));
-        if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+        for (int j = 0; j < KPT; ++j) kb[j] = s_stage[tid + j * THREADS];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = (kb[j] >> shift) & 255u;
+            st_stream(keys_out + (s_gbase[d] + tid + j * THREADS), from_bits<KT>(kb[j]));
+            if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t i = tid + j * THREADS;
+            const uint32_t kb = s_stage[i];
+            const uint32_t d = (kb >> shift) & 255u;
+            uint32_t o = s_gbase[d] + i;
+            if (reverse) o = n - 1u - o;
+            if (GS_EXP & 1) o = (tile_base + i) % n;  // ablation: positions are meaningless without the look-back
+            if (GS_EXP & 256) o = o % n;
+            if (full || (i >= head && i < head + count)) st_stream(keys_out + o, from_bits<KT>(kb));
+            if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+        }
     }
     GS_TRACE(6);
 
@@ -1111,13 +1125,22 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 if (my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
         }
         __syncthreads();
+        if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+            V vv[KPT];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t i = tid + j * THREADS;
-            uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
-            if (reverse) o = n - 1u - o;
-            if (GS_EXP & 1) o = (tile_base + i) % n;
-            if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
+            for (int j = 0; j < KPT; ++j) vv[j] = s_vstage[tid + j * THREADS];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                st_stream(vals_out + (s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + tid + j * THREADS), vv[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t i = tid + j * THREADS;
+                uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
+                if (reverse) o = n - 1u - o;
+                if (GS_EXP & 1) o = (tile_base + i) % n;
+                if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
+            }
         }
     }
     if (GS_UNLIKELY(cnt_h != 0xffffffffu && !(GS_EXP & 32))) {  // hand the tile's counts to the next pass
