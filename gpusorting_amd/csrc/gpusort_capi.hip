@@ -69,8 +69,9 @@ struct Shape {
 const Shape g_shapes[] = {
     GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
     GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
+    GS_FULL(512, 16),   // mid sizes (n <= MID_KEYS): 8192-key tiles, shorter per-tile latency, more workgroups
 #ifndef GS_NO_TUNING_SHAPES
-    GS_U32ONLY(512, 16), GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
+    GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
 #endif
 };
 constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
@@ -85,6 +86,8 @@ using gs::SLAB_INFO;
 using gs::SLAB_STATUS;
 
 constexpr uint32_t MIN_TILE = 4096;  // smallest tile of any compiled shape (sizing of the slab)
+constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= MID_KEYS unless the caller picked a shape
+constexpr uint32_t MID_KEYS = 1u << 23;  // profiles/r01_mid_sweep_shapes.txt: 512x16 wins up to 2^23 keys (-20 % at 2^14..2^18)
 
 }  // namespace
 
@@ -93,6 +96,7 @@ struct gs_onesweep {
     gs_mode mode;
     uint32_t value_bytes;
     int shape;
+    int shape_auto;  // 1 = the library picks (mid sizes use MID_SHAPE); 0 after gs_onesweep_set_shape / GPUSORT_SHAPE
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int heavy;       // heavy-value position slices in keys-only sorts: 1 on (default), 0 off
@@ -140,9 +144,9 @@ struct PassPlan {
     uint32_t grid, desc_stride;
 };
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
-                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0) {
+                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
-    const Shape& sh = g_shapes[h->shape];
+    const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
     const uint32_t rows = tiles + 2 * gs::MAXCH + 2;  // every chain: its tiles (+1 partial) + row 0
@@ -198,7 +202,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         // the single-tile kernel has no spin and cannot time out
         return GS_OK;
     }
-    const Shape& sh = g_shapes[h->shape];
+    const int shape = (h->shape_auto && n <= MID_KEYS) ? MID_SHAPE : h->shape;
+    const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     PassPlan plan;
@@ -210,7 +215,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // (measured: it pays for keys-only sorts; with values the counting costs more than the balanced chains
     // gain, profiles/r01_entropy_*); GPUSORT_HEAVY=0 switches it off
     const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && h->heavy != 0;  // compiled into the keys-only kernels only
-    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u));
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u), shape);
     if (st != GS_OK) return st;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
@@ -290,6 +295,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->mode = mode;
     h->value_bytes = value_bytes;
     h->shape = (mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0;
+    h->shape_auto = 1;
     h->rank_mode = 0;
     h->small_path = 1;
     if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
@@ -316,7 +322,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
         int t = 0, k = 0;
         if (sscanf(env, "%dx%d", &t, &k) == 2)
             for (int i = 0; i < g_num_shapes; ++i)
-                if (g_shapes[i].threads == t && g_shapes[i].kpt == k) h->shape = i;
+                if (g_shapes[i].threads == t && g_shapes[i].kpt == k) { h->shape = i; h->shape_auto = 0; }
     }
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
@@ -347,6 +353,7 @@ gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_
     for (int i = 0; i < g_num_shapes; ++i)
         if ((uint32_t)g_shapes[i].threads == threads && (uint32_t)g_shapes[i].kpt == keys_per_thread) {
             h->shape = i;
+            h->shape_auto = 0;
             return GS_OK;
         }
     return GS_ERR_ARG;
