@@ -121,12 +121,12 @@ size_t slab_words_for(uint32_t max_keys) {
     return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
 }
 
-using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t);
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t);
 template <int KT>
-void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* hist, uint32_t n, uint32_t seg_len0,
-                 uint32_t p0, uint32_t np) {
-    hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, hist, n,
-                       seg_len0, p0, np);
+void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n,
+                 uint32_t seg_len0, uint32_t p0, uint32_t np) {
+    hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, slab,
+                       used_words, n, seg_len0, p0, np);
 }
 const HistLauncher g_hist[3] = {launch_hist<0>, launch_hist<1>, launch_hist<2>};
 
@@ -154,13 +154,13 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const size_t used_words = SLAB_DESC + (size_t)np * desc_stride;
     // position segments of the first pass: equal, multiples of the histogram chunk
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
+    // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
-    GS_HIP(hipMemsetAsync(h->slab, 0, used_words * sizeof(uint32_t), s));
+    if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
+    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
-    if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
-    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab + SLAB_HIST, n, seg_len0, p0, np);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
     hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
                        h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan);
@@ -221,7 +221,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     void* v[2] = {d_vals, d_alt_vals};
     for (uint32_t p = 0; p < 4; ++p) {
         const uint32_t a = dyn ? 0u : (p & 1u);
-        const uint32_t mode = dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u);
+        const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
         fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
            h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
            h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
@@ -463,6 +463,7 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
     if (st != GS_OK) return st;
     const size_t words = 4 * (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t q = 0; q < 4; ++q)  // digit totals = joint histogram summed over chains
         for (uint32_t d = 0; d < gs::RADIX; ++d) {
@@ -495,7 +496,7 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
     fn(s, plan.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, pass * 8,
-       reverse_index ? 1u : 0u);
+       (reverse_index ? 1u : 0u) | 4u);
     GS_HIP(hipGetLastError());
     if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
         for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
@@ -514,6 +515,7 @@ gs_status gs_onesweep_msd_prepare(gs_onesweep* h, const void* d_keys, uint32_t n
     if (st != GS_OK) return st;
     const size_t words = (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // msd_partition may never be called
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t d = 0; d < gs::RADIX; ++d) {
         uint32_t g = 0;
@@ -543,7 +545,7 @@ gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     fn(s, h->msd_grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
-       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, 24, 0u);
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, 24, 4u);
     GS_HIP(hipGetLastError());
     h->msd_keys = nullptr;  // the scan state is consumed
     h->profile_pending = false;

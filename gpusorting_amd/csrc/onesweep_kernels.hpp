@@ -146,6 +146,7 @@ constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + 4 * NCH * RADIX;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 constexpr uint32_t SLAB_DESC = SLAB_HSUB + 4 * HSUB_STRIDE;
+static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif
@@ -243,10 +244,25 @@ __host__ __device__ constexpr uint32_t hist_index(uint32_t q, uint32_t d, uint32
 
 template <int KT>
 __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
-                                                                         uint32_t* hist, uint32_t n,
-                                                                         uint32_t seg_len0, uint32_t p0, uint32_t np) {
+                                                                         uint32_t* slab, size_t slab_used_words,
+                                                                         uint32_t n, uint32_t seg_len0, uint32_t p0,
+                                                                         uint32_t np) {
     __shared__ uint32_t s_h[4 * NCH * RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t* hist = slab + SLAB_HIST;
+    // This kernel is also the sort's CLEAR (reference: ClearMemory, OneSweepDispatcher.cuh:301-309): it zeroes the
+    // scan state nobody reads before it ends — ticket counters, status, info, slice counts, descriptors — as
+    // 16-byte grid-stride stores next to its read stream; a separate memset was one more launch (5 us of a 50 us
+    // sort at mid sizes).  The HIST region is zero whenever no call is in flight: the first DigitBinningPass
+    // launched after the Scan re-zeroes it (mode bit 2).
+    {
+        uint4* a = reinterpret_cast<uint4*>(slab);
+        const size_t na = SLAB_HIST / 4, b0 = SLAB_HSUB / 4, nb = slab_used_words / 4;  // all multiples of 4 words
+        const size_t stride = (size_t)gridDim.x * GHIST_THREADS;
+        const uint4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = (size_t)blockIdx.x * GHIST_THREADS + tid; i < na; i += stride) a[i] = z;
+        for (size_t i = b0 + (size_t)blockIdx.x * GHIST_THREADS + tid; i < nb; i += stride) a[i] = z;
+    }
     const uint32_t bins = np * NCH * RADIX;
     for (uint32_t i = tid; i < bins; i += GHIST_THREADS) s_h[i] = 0;
     __syncthreads();
@@ -569,7 +585,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     uint32_t* status, uint32_t n, uint32_t shift,
     uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
-                    on the last pass that runs (PF_LAST)*/) {
+                    on the last pass that runs (PF_LAST); bit2: zero the HIST region*/) {
     using Cfg = BinCfg<THREADS, KPT, VB>;
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
@@ -590,6 +606,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+    if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
+        constexpr uint32_t HWORDS = 4 * NCH * RADIX;
+        const uint32_t i = blockIdx.x * THREADS + tid;
+        if (i < HWORDS / 4) reinterpret_cast<uint4*>(hsub - HWORDS)[i] = uint4{0u, 0u, 0u, 0u};
+    }
     if constexpr (Cfg::HEAVY)
         for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
 #if (GS_EXP & 2)

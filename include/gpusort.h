@@ -156,7 +156,8 @@ gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void*
 /* ---- profiling hook --------------------------------------------------------
  * Replaces the cudaEvent pair of BatchTiming* (OneSweepDispatcher.cuh:207-229)
  * with per-kernel HIP events recorded on the sort's own stream.
- * Slots: 0 state clear, 1 GlobalHistogram, 2 Scan, 3..6 DigitBinningPass 0..3, 7 whole sort. */
+ * Slots: 0 state clear (0 since the clear is folded into the GlobalHistogram kernel), 1 GlobalHistogram,
+ * 2 Scan, 3..6 DigitBinningPass 0..3, 7 whole sort. */
 #define GS_PROFILE_SLOTS 8
 gs_status gs_onesweep_set_profiling(gs_onesweep* h, int enabled);
 /* Synchronises the last profiled sort and returns milliseconds per slot. */
