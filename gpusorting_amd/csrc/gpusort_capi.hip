@@ -177,23 +177,34 @@ gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n,
     return GS_OK;
 }
 
-// single-tile fast path (n <= gs::SMALL_TILE): one launch, no scan state
+// single-tile fast path: one launch, no scan state.  Three tile sizes: 8192 slots (every mode), 16384
+// (keys-only and 4-byte values), 32768 (keys-only) — what fits 160 KiB of LDS.
 using SmallLauncher = void (*)(hipStream_t, uint32_t*, void*, uint32_t, uint32_t);
-template <int VB, int KT, int RANK>
+template <int T, int K, int VB, int KT, int RANK>
 void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_t descending) {
-    hipLaunchKernelGGL((gs::small_sort_kernel<VB, KT, RANK>), dim3(1), dim3(gs::SMALL_THREADS), 0, s, keys, vals, n,
-                       descending);
+    hipLaunchKernelGGL((gs::small_sort_kernel<T, K, VB, KT, RANK>), dim3(1), dim3(T), 0, s, keys, vals, n, descending);
 }
-#define GS_SMALL_ROW(VB, R) {launch_small<VB, 0, R>, launch_small<VB, 1, R>, launch_small<VB, 2, R>}
-const SmallLauncher g_small[2][3][3] = {{GS_SMALL_ROW(0, 0), GS_SMALL_ROW(4, 0), GS_SMALL_ROW(8, 0)},
-                                        {GS_SMALL_ROW(0, 1), GS_SMALL_ROW(4, 1), GS_SMALL_ROW(8, 1)}};
+#define GS_SMALL_ROW(T, K, VB, R) {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>}
+#define GS_SMALL_NONE {nullptr, nullptr, nullptr}
+// [size class][rank mode][vb index][key type]
+const SmallLauncher g_small[3][2][3][3] = {
+    {{GS_SMALL_ROW(512, 16, 0, 0), GS_SMALL_ROW(512, 16, 4, 0), GS_SMALL_ROW(512, 16, 8, 0)},
+     {GS_SMALL_ROW(512, 16, 0, 1), GS_SMALL_ROW(512, 16, 4, 1), GS_SMALL_ROW(512, 16, 8, 1)}},
+    {{GS_SMALL_ROW(1024, 16, 0, 0), GS_SMALL_ROW(1024, 16, 4, 0), GS_SMALL_NONE},
+     {GS_SMALL_ROW(1024, 16, 0, 1), GS_SMALL_ROW(1024, 16, 4, 1), GS_SMALL_NONE}},
+    {{GS_SMALL_ROW(1024, 32, 0, 0), GS_SMALL_NONE, GS_SMALL_NONE},
+     {GS_SMALL_ROW(1024, 32, 0, 1), GS_SMALL_NONE, GS_SMALL_NONE}},
+};
+inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_key_type kt) {
+    const int cls = n <= 8192 ? 0 : n <= 16384 ? 1 : n <= 32768 ? 2 : 3;
+    return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;
+}
 
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
-    if (n <= gs::SMALL_TILE && h->small_path) {
+    if (SmallLauncher small = h->small_path ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
-        g_small[h->rank_mode][vb_index(vb)][kt](s, static_cast<uint32_t*>(d_keys), d_vals, n,
-                                                  order == GS_ORDER_DESCENDING ? 1u : 0u);
+        small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
         if (h->profiling)  // everything is charged to slot 0 (and the total)
             for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
         GS_HIP(hipGetLastError());

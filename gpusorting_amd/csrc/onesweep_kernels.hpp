@@ -1192,15 +1192,18 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 // Descending = final index reversal (SortCommon.hlsl:594-597).  Slots >= n hold
 // all-one dummy keys that stay behind every real key in every pass.
 // ---------------------------------------------------------------------------
-constexpr int SMALL_THREADS = 512;
-constexpr int SMALL_KPT = 16;
-constexpr uint32_t SMALL_TILE = SMALL_THREADS * SMALL_KPT;  // 8192
+// Shapes: 512 x 16 (8192 slots, every value type), 1024 x 16 (16 384: keys-only and 4-byte values) and
+// 1024 x 32 (32 768: keys-only) — as far as 160 KiB of LDS go.
+constexpr uint32_t SMALL_TILE = 512 * 16;         // 8192: the size every mode can sort in one workgroup
+constexpr uint32_t SMALL_TILE_MAX = 1024 * 32;    // largest single-tile sort (keys-only)
 
-template <int VB, int KT, int RANK>
+template <int SMALL_THREADS, int SMALL_KPT, int VB, int KT, int RANK>
 __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* keys, void* vals_, uint32_t n,
                                                                    uint32_t descending) {
     using V = typename ValT<VB>::type;
     constexpr int KPT = SMALL_KPT, WAVES = SMALL_THREADS / 64;
+    constexpr uint32_t SMALL_TILE = SMALL_THREADS * SMALL_KPT;
+    static_assert(SMALL_TILE * (4 + (VB == 8 ? 8 : VB)) + WAVES * RADIX * 4 + 64 <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[SMALL_TILE];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? SMALL_TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];

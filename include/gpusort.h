@@ -111,8 +111,9 @@ uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
  * returning LDS atomic per key, valid only if gs_selftest_lds_atomic_order()
  * reports 0 failures on this device. */
 gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
-/* n <= 8192 is sorted by ONE workgroup in one launch (all four passes in LDS) unless this is
- * switched off (tests use 0 to push small sizes through the tiled path as well). */
+/* Small inputs are sorted by ONE workgroup in one launch (all four passes in LDS): n <= 8192 in every
+ * mode, n <= 16384 for keys-only and 4-byte values, n <= 32768 for keys-only — unless this is switched off
+ * (tests use 0 to push small sizes through the tiled path as well). */
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
 /* A pass whose digit is the same for every key (e.g. the upper bytes of 16-bit keys) is the
  * identity permutation.  The Scan kernel sees that in the histogram and drops such passes in

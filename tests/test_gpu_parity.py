@@ -340,9 +340,11 @@ def test_sharded_path_single_rank_nccl(gpu, oracle, pairs):
 @pytest.mark.parametrize("small_path", [True, False])
 @pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (0, 2, 1), (4, 1, 1), (8, 0, 0), (4, 0, 0)])
 def test_single_tile_path_and_tiled_path_agree(gpu, oracle, small_path, vb, kt, order):
-    """n <= 8192 takes the one-launch single-tile kernel; with it switched off the same sizes go through
-    clear + histogram + scan + 4 passes.  Both must equal the oracle (stability: value = index)."""
-    for n, andc in ((1, 0), (2, 0), (63, 1), (64, 0), (65, 4), (1000, 0), (4097, 2), (8191, 0), (8192, 3), (8193, 0)):
+    """Small n takes the one-launch single-tile kernel (8192 slots for every mode, 16384 for keys-only and
+    4-byte values, 32768 for keys-only); with it switched off the same sizes go through histogram + scan +
+    4 passes.  Both must equal the oracle (stability: value = index)."""
+    for n, andc in ((1, 0), (2, 0), (63, 1), (64, 0), (65, 4), (1000, 0), (4097, 2), (8191, 0), (8192, 3), (8193, 0),
+                    (12345, 1), (16384, 0), (16385, 4), (30000, 0), (32768, 2), (32769, 0)):
         keys = oracle.init_random(n, 7 * n + 3, andc)
         vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
         s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
