@@ -25,6 +25,11 @@
 //     multi-split as the guaranteed fallback.
 //   * descriptors are single dwords {count:30, flag:2} accessed with relaxed
 //     agent-scope atomics (sc1): the data IS the flag, no fences.
+//   * everything is decided on the device, nothing needs a host round trip: the Scan kernel plans the passes
+//     (identity passes are dropped in pairs, a skewed pass ranks with wave-aggregated adds, a digit value holding
+//     most keys gets its run split into position chains in the next pass), and a look-back that waits too long
+//     recounts the missing tile itself, so no workgroup depends on another's progress for more than a bounded time.
+//   * a sort is 6 launches: GlobalHistogram (which also clears the scan state), Scan, 4 x DigitBinningPass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,9 +51,10 @@ constexpr uint32_t STATUS_TIMEOUT = 4;  // == GS_ERR_TIMEOUT
 #define GS_SPIN_LIMIT (1u << 21)
 #endif
 constexpr uint32_t SPIN_LIMIT = GS_SPIN_LIMIT;
-// GS_EXP & 8 (fault-injection build, cf. the reference's EmulatedDeadlocking.cu:36-37,339-345): tile 5 of
-// chain 3 never publishes its descriptor, as if its workgroup had stalled; every later tile of that chain
-// must run into the bounded spin, the sort must still finish, and gs_onesweep_check must say GS_ERR_TIMEOUT.
+// GS_EXP & 8 (fault-injection builds, cf. the reference's EmulatedDeadlocking.cu:36-37,339-345): tile 5 of
+// chain 3 never publishes its descriptor, as if its workgroup had stalled.  With the fallback (default) its
+// successors recount it and the sort is exact; with -DGS_FALLBACK=0 every later tile of that chain runs into the
+// bounded spin, the sort still finishes, and gs_onesweep_check says GS_ERR_TIMEOUT.
 #define GS_FAULT_TILE(chain, tile) (((GS_EXP)&8) && (chain) == 3u && (tile) == 5u)
 
 #ifndef GS_NCHAINS
@@ -58,7 +64,9 @@ constexpr uint32_t NCH = GS_NCHAINS;
 static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must be a power of two <= 32");
 
 #ifndef GS_EXP
-#define GS_EXP 0  // experiment flags (ablation builds only): 1 = no look-back wait
+#define GS_EXP 0  // experiment flags (ablation / instrumented builds only): 1 no look-back wait (sequential output),
+                  // 2 per-tile phase trace, 4 histogram streams only, 8 fault injection, 16/32 heavy-value counting /
+                  // flush off, 64 heavy layout not used (counting still runs), 256 no wait with the real scatter shape
 #endif
 // GS_EXP & 2: per-tile phase timestamps (10 ns ticks, lane 0 of wave 0) into the buffer whose
 // address the host stored in the slab at STATUS+8; 8 words per (pass, block).
