@@ -94,3 +94,26 @@ def test_2pow24_typed_keys_exact(gpu, oracle, kt, order, vb):
     if vb:
         np.testing.assert_array_equal(dv.cpu().numpy().view(vals.dtype), rv)
     s.close()
+
+
+@pytest.mark.parametrize("andc,pairs", [(4, False), (3, False), (2, False), (4, True)])
+def test_2pow28_low_entropy_properties(gpu, andc, pairs):
+    """BASELINE configs[4]'s entropy presets at full size (presets 3-5): skewed ranking, and for keys-only
+    sorts the heavy-value position slices, on 16 384 tiles.  Properties: no inversion, permutation-invariant
+    checksums, all digit histograms preserved, payload travelled with its key."""
+    import torch
+    n = 1 << 28
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    dv = torch.empty(n, dtype=torch.int64, device="cuda") if pairs else None
+    gpu.init_random(dk, 28 + andc, andc, dv)
+    before = _checksums(dk)
+    s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if pairs else gpu.MODE_KEYS_ONLY, value_bytes=8 if pairs else 0)
+    h_before = s.global_histogram(dk)
+    s.sort(dk, dv)
+    s.check()
+    assert gpu.validate(dk) == 0
+    assert _checksums(dk) == before
+    np.testing.assert_array_equal(s.global_histogram(dk), h_before)
+    if pairs:  # the generator sets value = zero-extended key (UtilityKernels.cuh:157-168)
+        assert bool(((dk.to(torch.int64) & 0xFFFFFFFF) == dv).all().item())
+    s.close()

@@ -509,3 +509,49 @@ def test_heavy_value_position_slices(gpu, oracle, vb, kt, order):
             rk, rv = oracle.std_sort(keys, kt, order, vals)
             np.testing.assert_array_equal(ok, rk, err_msg=name)
             np.testing.assert_array_equal(ov, rv, err_msg=name)
+
+
+def _fuzz_keys(rng, oracle, n):
+    kind = int(rng.integers(0, 8))
+    u = oracle.init_random(n, int(rng.integers(1, 1 << 30)), 0)
+    if kind == 0:
+        return u
+    if kind == 1:
+        return oracle.init_random(n, int(rng.integers(1, 1 << 30)), int(rng.integers(1, 5)))
+    if kind == 2:  # few distinct values
+        pool = rng.integers(0, 1 << 32, size=int(rng.integers(1, 9)), dtype=np.uint64).astype(np.uint32)
+        return pool[rng.integers(0, pool.size, size=n)]
+    if kind == 3:  # sorted / reversed / nearly sorted
+        s = np.sort(u)
+        return s if rng.random() < 0.5 else s[::-1].copy()
+    if kind == 4:  # random constant bytes
+        mask = np.uint32(sum(0xFF << (8 * b) for b in range(4) if rng.random() < 0.5))
+        return (u & mask) | (np.uint32(rng.integers(0, 1 << 32, dtype=np.uint64)) & ~mask)
+    if kind == 5:  # one heavy value per byte with random weight
+        k = u.copy()
+        for b in range(4):
+            pick = rng.random(n) < rng.random()
+            hv = np.uint32(int(rng.integers(0, 256)) << (8 * b))
+            k = np.where(pick, (k & np.uint32(~(0xFF << (8 * b)) & 0xFFFFFFFF)) | hv, k)
+        return k.astype(np.uint32)
+    if kind == 6:  # small range
+        return (u % np.uint32(int(rng.integers(1, 70000)))).astype(np.uint32)
+    return (u >> np.uint32(int(rng.integers(0, 31)))).astype(np.uint32)
+
+
+def test_fuzz_against_oracle(gpu, oracle):
+    """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, heavy layout),
+    distributions, key types, orders and value widths; every case bit-exact against the oracle."""
+    rng = np.random.default_rng(20260925)
+    for case in range(48):
+        top = (40000, 300000, 6 << 20)[case % 3]
+        n = int(rng.integers(1, top))
+        keys = np.ascontiguousarray(_fuzz_keys(rng, oracle, n), dtype=np.uint32)
+        kt, order, vb = int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.choice([0, 0, 4, 8]))
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ok, ov = _gpu_sort(gpu, keys, kt, order, vals)
+        ref = oracle.std_sort(keys, kt, order, vals)
+        rk, rv = (ref, None) if vals is None else ref
+        np.testing.assert_array_equal(ok, rk, err_msg=f"case {case}: n={n} kt={kt} order={order} vb={vb}")
+        if vals is not None:
+            np.testing.assert_array_equal(ov, rv, err_msg=f"case {case} values: n={n} kt={kt} order={order} vb={vb}")
