@@ -542,8 +542,8 @@ def _fuzz_keys(rng, oracle, n):
 def test_fuzz_against_oracle(gpu, oracle):
     """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, heavy layout),
     distributions, key types, orders and value widths; every case bit-exact against the oracle."""
-    rng = np.random.default_rng(20260925)
-    for case in range(48):
+    rng = np.random.default_rng(int(os.environ.get("GPUSORT_FUZZ_SEED", "20260925")))
+    for case in range(int(os.environ.get("GPUSORT_FUZZ_CASES", "48"))):  # longer hunts: set the two variables
         top = (40000, 300000, 6 << 20)[case % 3]
         n = int(rng.integers(1, top))
         keys = np.ascontiguousarray(_fuzz_keys(rng, oracle, n), dtype=np.uint32)
