@@ -104,6 +104,9 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
                     // position sub-chains; the joint counts those chains need are gathered by the pass that writes
                     // the region (see "heavy digit" in DESIGN.md).  0 = digit-group chains only.
 #endif
+#ifndef GS_FUSED_PAIRS
+#define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
+#endif
 #ifndef GS_HEAVY_SHARE
 #define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
                            // gain nothing over the digit-group chains and the counting still costs
@@ -564,7 +567,10 @@ template <int THREADS, int KPT, int VB>
 struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
-    static constexpr int STAGE_BYTES = TILE * (VB == 8 ? 8 : 4);
+    // 4-byte values travel WITH their keys: loaded up front, staged as 8-byte (key, value) slots, scattered in
+    // the same loop — no second staging round, no saved positions/digits, two barriers fewer per tile
+    static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4;
+    static constexpr int STAGE_BYTES = TILE * ((VB == 8 || FUSED) ? 8 : 4);
     // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
     static constexpr bool HEAVY = GS_HEAVY && VB == 0;
     static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
@@ -760,6 +766,21 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
     }
 
+    V val[VB != 0 ? KPT : 1];
+    if constexpr (Cfg::FUSED) {  // the values come along from the start
+        const V* vals_in = reinterpret_cast<const V*>(vals_in_);
+        if (GS_LIKELY(full)) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = my_base + i * 64u;
+                val[i] = ld_stream<false>(vals_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+            }
+        }
+    }
+
     // ---- rank every key among the keys of its digit inside this wave ----
     // offp[] holds two 16-bit ranks (later: tile-local positions) per register.
     uint32_t* whist = s_whist + wave * RADIX;
@@ -926,10 +947,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
             const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
-            s_stage[lpos] = key[i];
-            if constexpr (VB != 0) {  // values follow the same positions later
-                if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
-                else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+            if constexpr (Cfg::FUSED) {
+                reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], val[i]};
+            } else {
+                s_stage[lpos] = key[i];
+                if constexpr (VB != 0) {  // values follow the same positions later
+                    if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
+                    else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+                }
             }
         }
     } else {
@@ -937,10 +962,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
             const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
-            if (my_base + i * 64u < hi) s_stage[lpos] = key[i];
-            if constexpr (VB != 0) {
-                if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
-                else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+            if constexpr (Cfg::FUSED) {
+                if (my_base + i * 64u < hi) reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], val[i]};
+            } else {
+                if (my_base + i * 64u < hi) s_stage[lpos] = key[i];
+                if constexpr (VB != 0) {
+                    if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
+                    else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
+                }
             }
         }
     }
@@ -1064,8 +1093,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----
-    V val[VB != 0 ? KPT : 1];
-    if constexpr (VB != 0) {
+    if constexpr (VB != 0 && !Cfg::FUSED) {
         const V* vals_in = reinterpret_cast<const V*>(vals_in_);
         if (GS_LIKELY(full)) {
 #pragma unroll
@@ -1113,7 +1141,34 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int j = 0; j < KPT / 4; ++j) digs[j] = 0;
     }
-    if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+    if constexpr (Cfg::FUSED) {
+        V* vals_out = reinterpret_cast<V*>(vals_out_);
+        const uint2* s_kv = reinterpret_cast<const uint2*>(s_raw);
+        if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+            uint2 kv[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) kv[j] = s_kv[tid + j * THREADS];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t o = s_gbase[(kv[j].x >> shift) & 255u] + tid + j * THREADS;
+                st_stream(keys_out + o, from_bits<KT>(kv[j].x));
+                st_stream(vals_out + o, kv[j].y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t i = tid + j * THREADS;
+                const uint2 kv = s_kv[i];
+                uint32_t o = s_gbase[(kv.x >> shift) & 255u] + i;
+                if (reverse) o = n - 1u - o;
+                if (GS_EXP & 1) o = (tile_base + i) % n;
+                if (full || (i >= head && i < head + count)) {
+                    st_stream(keys_out + o, from_bits<KT>(kv.x));
+                    st_stream(vals_out + o, kv.y);
+                }
+            }
+        }
+    } else if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
         // the common case as straight-line code: all stage reads first, then the base look-ups, then the stores
         // (with the masks and the reversal in the loop every key got its own branches and LDS round trips)
         uint32_t kb[KPT];
@@ -1141,7 +1196,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     GS_TRACE(6);
 
-    if constexpr (VB != 0) {
+    if constexpr (VB != 0 && !Cfg::FUSED) {
         V* vals_out = reinterpret_cast<V*>(vals_out_);
         V* s_vstage = reinterpret_cast<V*>(s_raw);
         __syncthreads();  // everyone is done reading the key stage
