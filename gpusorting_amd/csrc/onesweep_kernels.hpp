@@ -569,8 +569,10 @@ struct BinCfg {
     static constexpr int TILE = THREADS * KPT;
     // 4-byte values travel WITH their keys: loaded up front, staged as 8-byte (key, value) slots, scattered in
     // the same loop — no second staging round, no saved positions/digits, two barriers fewer per tile
+    // (8-byte values the same way need a 512 x 24 tile, 12 288 pairs x 12 B = 144 KiB in two LDS arrays: measured
+    //  5.975 vs 6.014 ms, not worth a shape of its own; the code path stays generic in VB)
     static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4;
-    static constexpr int STAGE_BYTES = TILE * ((VB == 8 || FUSED) ? 8 : 4);
+    static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : TILE * (VB == 8 ? 8 : 4);
     // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
     static constexpr bool HEAVY = GS_HEAVY && VB == 0;
     static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
@@ -942,13 +944,22 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // ---- stage keys in LDS, sorted by digit (stable) ----
     // mask_tail: the tile's trailing dummies were not ranked (above) and are not staged
     const bool mask_tail = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
+    // fused pairs: slot = (key, value); 4-byte values as one 8-byte LDS word, 8-byte values in a second array
+    auto stage_pair = [&](uint32_t slot, uint32_t k, V v) {
+        if constexpr (VB == 4) {
+            reinterpret_cast<uint2*>(s_raw)[slot] = uint2{k, (uint32_t)v};
+        } else {
+            s_stage[slot] = k;
+            reinterpret_cast<V*>(s_raw + TILE * 4)[slot] = v;
+        }
+    };
     if (GS_LIKELY(!mask_tail)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
             const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
             if constexpr (Cfg::FUSED) {
-                reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], val[i]};
+                stage_pair(lpos, key[i], val[i]);
             } else {
                 s_stage[lpos] = key[i];
                 if constexpr (VB != 0) {  // values follow the same positions later
@@ -963,7 +974,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             const uint32_t d = (key[i] >> shift) & 255u;
             const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
             if constexpr (Cfg::FUSED) {
-                if (my_base + i * 64u < hi) reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], val[i]};
+                if (my_base + i * 64u < hi) stage_pair(lpos, key[i], val[i]);
             } else {
                 if (my_base + i * 64u < hi) s_stage[lpos] = key[i];
                 if constexpr (VB != 0) {
@@ -1143,28 +1154,40 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     if constexpr (Cfg::FUSED) {
         V* vals_out = reinterpret_cast<V*>(vals_out_);
-        const uint2* s_kv = reinterpret_cast<const uint2*>(s_raw);
+        auto load_pair = [&](uint32_t slot, uint32_t& k, V& v) {
+            if constexpr (VB == 4) {
+                const uint2 kv = reinterpret_cast<const uint2*>(s_raw)[slot];
+                k = kv.x;
+                v = kv.y;
+            } else {
+                k = s_stage[slot];
+                v = reinterpret_cast<const V*>(s_raw + TILE * 4)[slot];
+            }
+        };
         if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
-            uint2 kv[KPT];
+            uint32_t kk[KPT];
+            V vv[KPT];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) kv[j] = s_kv[tid + j * THREADS];
+            for (int j = 0; j < KPT; ++j) load_pair(tid + j * THREADS, kk[j], vv[j]);
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const uint32_t o = s_gbase[(kv[j].x >> shift) & 255u] + tid + j * THREADS;
-                st_stream(keys_out + o, from_bits<KT>(kv[j].x));
-                st_stream(vals_out + o, kv[j].y);
+                const uint32_t o = s_gbase[(kk[j] >> shift) & 255u] + tid + j * THREADS;
+                st_stream(keys_out + o, from_bits<KT>(kk[j]));
+                st_stream(vals_out + o, vv[j]);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const uint32_t i = tid + j * THREADS;
-                const uint2 kv = s_kv[i];
-                uint32_t o = s_gbase[(kv.x >> shift) & 255u] + i;
+                uint32_t k;
+                V v;
+                load_pair(i, k, v);
+                uint32_t o = s_gbase[(k >> shift) & 255u] + i;
                 if (reverse) o = n - 1u - o;
                 if (GS_EXP & 1) o = (tile_base + i) % n;
                 if (full || (i >= head && i < head + count)) {
-                    st_stream(keys_out + o, from_bits<KT>(kv.x));
-                    st_stream(vals_out + o, kv.y);
+                    st_stream(keys_out + o, from_bits<KT>(k));
+                    st_stream(vals_out + o, v);
                 }
             }
         }
