@@ -1147,6 +1147,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
 
     // ---- scatter runs to global memory (slot i of the stage -> s_gbase[digit] + i) ----
+    // descending (last pass): index n-1-o == (o ^ ~0) + n, folded into two uniform operands so the straight-line
+    // scatter serves both orders
+    const uint32_t rev_xor = reverse ? 0xffffffffu : 0u, rev_add = reverse ? n : 0u;
     uint32_t digs[VB != 0 ? KPT / 4 : 1];  // digit of stage slot tid + j*THREADS, 4 per register (value phase)
     if constexpr (VB != 0) {
 #pragma unroll
@@ -1164,14 +1167,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 v = reinterpret_cast<const V*>(s_raw + TILE * 4)[slot];
             }
         };
-        if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+        if (GS_LIKELY(full) && !(GS_EXP & 257)) {
             uint32_t kk[KPT];
             V vv[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) load_pair(tid + j * THREADS, kk[j], vv[j]);
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const uint32_t o = s_gbase[(kk[j] >> shift) & 255u] + tid + j * THREADS;
+                const uint32_t o = ((s_gbase[(kk[j] >> shift) & 255u] + tid + j * THREADS) ^ rev_xor) + rev_add;
                 st_stream(keys_out + o, from_bits<KT>(kk[j]));
                 st_stream(vals_out + o, vv[j]);
             }
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 }
             }
         }
-    } else if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+    } else if (GS_LIKELY(full) && !(GS_EXP & 257)) {
         // the common case as straight-line code: all stage reads first, then the base look-ups, then the stores
         // (with the masks and the reversal in the loop every key got its own branches and LDS round trips)
         uint32_t kb[KPT];
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t d = (kb[j] >> shift) & 255u;
-            st_stream(keys_out + (s_gbase[d] + tid + j * THREADS), from_bits<KT>(kb[j]));
+            st_stream(keys_out + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
             if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
         }
     } else {
@@ -1232,13 +1235,13 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 if (my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
         }
         __syncthreads();
-        if (GS_LIKELY(full && !reverse) && !(GS_EXP & 257)) {
+        if (GS_LIKELY(full) && !(GS_EXP & 257)) {
             V vv[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) vv[j] = s_vstage[tid + j * THREADS];
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
-                st_stream(vals_out + (s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + tid + j * THREADS), vv[j]);
+                st_stream(vals_out + (((s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + tid + j * THREADS) ^ rev_xor) + rev_add), vv[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
