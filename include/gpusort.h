@@ -128,6 +128,9 @@ gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* 
  * look-back (memory floor of the tile shape). */
 gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads,
                               uint32_t keys_per_thread, void* stream);
+/* Instrumented builds only (-DGS_EXP=2, tools/trace_tiles.py): device buffer of 4 passes x grid x 8 words that
+ * receives per-tile phase timestamps.  A no-op in the product build. */
+gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf);
 
 /* ---- structural entry points (parity tests, MSD split) --------------------
  * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
