@@ -25,6 +25,20 @@ def test_header_symbols_are_exported_and_bound():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes binding and header disagree"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """The boundary is exactly include/gpusort.h: no stray gs_* entry points in the dynamic symbol table."""
+    import shutil
+    import subprocess
+    from gpusorting_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if out.returncode != 0:
+        import pytest
+        pytest.skip("no nm on this box")
+    exported = sorted({ln.split()[-1] for ln in out.stdout.splitlines() if ln.split() and ln.split()[-1].startswith("gs_")})
+    assert exported == _declared_symbols()
+
+
 def test_version_and_status_strings():
     from gpusorting_amd import _lib
     lib = _lib.load()
