@@ -91,6 +91,37 @@ class ShardedOneSweep:
             self._recv_v = torch.empty(self.capacity, dtype=dt, device=dev)
         self._gather = torch.empty(self.world * 256, dtype=torch.int64, device=dev)
         self.last_counts = None
+        # gloo cannot move device memory: with that backend and a GPU engine the two collectives are staged
+        # through host tensors (test configuration: several ranks sharing one GPU; the product backend is RCCL)
+        self._host_staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+
+    def _all_gather(self, out, inp):
+        if not self._host_staged:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+            return
+        parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(self.world)]
+        dist.all_gather(parts, inp.cpu(), group=self.group)
+        out.copy_(torch.cat(parts))
+
+    def _all_to_all(self, out, inp, recv, send):
+        if not self._host_staged:
+            dist.all_to_all_single(out, inp, recv, send, group=self.group)
+            return
+        src = inp.cpu()
+        outs = [torch.empty(r, dtype=inp.dtype) for r in recv]
+        ins = list(torch.split(src, send))
+        # gloo has no all_to_all: point-to-point, lower rank sends first
+        reqs = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                outs[peer].copy_(ins[peer])
+            else:
+                reqs.append(dist.isend(ins[peer].contiguous(), peer, group=self.group))
+                reqs.append(dist.irecv(outs[peer], peer, group=self.group))
+        for r in reqs:
+            r.wait()
+        if out.numel():
+            out.copy_(torch.cat(outs))
 
     def sort(self, keys: torch.Tensor, n: int | None = None, values: torch.Tensor | None = None):
         """Sort the distributed array whose local shard is ``keys[:n]``.
@@ -109,7 +140,7 @@ class ShardedOneSweep:
 
         # 1-2: histograms of every rank, splitters, split sizes
         local = torch.from_numpy(eng.top_byte_histogram(keys, n)).to(self._gather.device)
-        dist.all_gather_into_tensor(self._gather, local, group=self.group)
+        self._all_gather(self._gather, local)
         table = self._gather.cpu().numpy().reshape(W, 256)          # [source, top byte]
         first_bin = msd_splitters(table.sum(axis=0).astype(np.uint64), W)
         csum = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(table, axis=1)], axis=1)
@@ -124,9 +155,9 @@ class ShardedOneSweep:
         # 3: group by destination (stable)
         eng.partition_by_top_byte(keys, self._part, n, values, self._part_v)
         # 4: bucket exchange
-        dist.all_to_all_single(self._recv[:n_recv], self._part[:n], recv, send, group=self.group)
+        self._all_to_all(self._recv[:n_recv], self._part[:n], recv, send)
         if values is not None:
-            dist.all_to_all_single(self._recv_v[:n_recv], self._part_v[:n], recv, send, group=self.group)
+            self._all_to_all(self._recv_v[:n_recv], self._part_v[:n], recv, send)
         # 5: local sort
         if n_recv:
             eng.sort(self._recv, n_recv, self._recv_v if values is not None else None)

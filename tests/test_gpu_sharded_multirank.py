@@ -1,0 +1,71 @@
+"""The multi-GPU pipeline with the REAL per-rank engine (libgpusort.so kernels) on world_size 2 and 3 — on a
+one-GPU box: the ranks share cuda:0 and talk over gloo (ShardedOneSweep stages the two collectives through host
+memory for that backend; RCCL refuses two ranks on one device).  Everything else is the product path: top-byte
+histogram + scan of the shard, splitters, stable split by destination, exchange, local 4-pass sort."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, shard, andc, pairs, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import gpusorting_amd as g
+    from gpusorting_amd.sharded import ShardedOneSweep
+    torch.cuda.set_device(0)
+    keys = torch.empty(shard, dtype=torch.int32, device="cuda")
+    g.init_random(keys, 10 + 1000 * rank, andc)
+    vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
+    k0 = keys.cpu().numpy().view(np.uint32).copy()
+    v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
+    s = ShardedOneSweep(shard, slack=3.0, pairs=pairs, value_bytes=4)   # HipLocalEngine
+    bk, bv, nb = s.sort(keys, values=vals)
+    torch.cuda.synchronize()
+    s.engine.sorter.check()
+    q.put((rank, k0, v0, bk.cpu().numpy().view(np.uint32).copy(), None if bv is None else bv.cpu().numpy().view(np.uint32).copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (1 << 20) + 77), (3, 0, True, 300001), (2, 1, True, (1 << 18) + 5)])
+def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([x[1] for x in got])
+    out_keys = np.concatenate([x[3] for x in got])
+    if not pairs:
+        np.testing.assert_array_equal(out_keys, np.sort(all_keys))
+    else:
+        all_vals = np.concatenate([x[2] for x in got])
+        out_vals = np.concatenate([x[4] for x in got])
+        perm = np.argsort(all_keys, kind="stable")   # global stable order: (rank, position)
+        np.testing.assert_array_equal(out_keys, all_keys[perm])
+        np.testing.assert_array_equal(out_vals, all_vals[perm])
+    for a, b in zip(got[:-1], got[1:]):              # buckets are contiguous ranges of the global order
+        if a[3].size and b[3].size:
+            assert a[3].max() <= b[3].min()
