@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--entropy", type=int, default=0, help="ENTROPY_PRESET index 0..4")
     ap.add_argument("--shape", type=str, default="", help="tile shape TxK (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-backend", type=str, default="", help="rehearsal of the N>1 code path on a one-GPU box: 'gloo' = "
+                    "every rank on cuda:0, collectives over gloo (host-staged); never used for reported numbers")
     ap.add_argument("--cpu-log2", type=int, default=26)
     return ap.parse_args()
 
@@ -96,12 +98,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_backend == "gloo"
+    torch.cuda.set_device(0 if dry else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if dry else "cuda"  # where the few scalar collectives of this script live
 
     import gpusorting_amd as g
     from gpusorting_amd.sharded import ShardedOneSweep
@@ -162,7 +169,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -174,7 +181,7 @@ def main():
     if dist is not None:
         lo = int(out_k[0].item()) & 0xFFFFFFFF if out_n else 0xFFFFFFFF
         hi = int(out_k[out_n - 1].item()) & 0xFFFFFFFF if out_n else 0
-        info = torch.tensor([out_n, lo, hi], dtype=torch.int64, device="cuda")
+        info = torch.tensor([out_n, lo, hi], dtype=torch.int64, device=coll_dev)
         allinfo = [torch.empty_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info)
         rows = [x.tolist() for x in allinfo]
@@ -223,7 +230,7 @@ def main():
         "metric": "GKeys/s uint32 OneSweep (whole sort: clear + GlobalHistogram + Scan + 4 DigitBinningPass)",
         "value": value, "unit": "GKeys/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32" if not pairs else f"u32 keys + u{8 * args.pairs} values", "data": "synthetic",
+        "dtype": "u32" if not pairs else f"u32 keys + u{8 * args.pairs} values", "data": "synthetic" if not dry else "synthetic (REHEARSAL: ranks share one GPU, gloo; not a measurement)",
         "config": {
             "workload": (f"2^{args.log2_keys} uniform-random uint32 {'pairs' if pairs else 'keys-only'} OneSweep, 1 MI355X "
                          f"(BASELINE configs[{2 if args.pairs == 4 else 4 if args.pairs == 8 else 1}])") if world == 1 else
