@@ -8,18 +8,25 @@
  *
  * PARITY PINNING STATUS
  *   - The reference (b0nes164/GPUSorting @ 2024_10_08) holds NO golden vector
- *     or known-answer test for this path and its sources
- *     (CUDA + PTX, D3D12/HLSL, Unity C#) cannot be built in this image, so
- *     no reference-produced output exists to pin against.
+ *     or known-answer test for this path.  Its SORT kernels
+ *     (CUDA + PTX warp code, D3D12/HLSL, Unity C#) cannot be built or run in
+ *     this image, so no reference-produced sort output exists to pin against.
  *   - The SORT RESULT is pinned by mathematical uniqueness: keys-only = the
  *     sorted multiset; pairs = the stable sort by key; descending = the exact
  *     reverse of the stable ascending result (reference
  *     GPUSortingD3D12/Shaders/SortCommon.hlsl:594-597,645-656).  It is
  *     cross-checked against two independent implementations (std::stable_sort
  *     here, numpy in tests/golden/make_golden.py).
- *   - The INPUT GENERATOR (InitRandom) is a restatement checked only against a
- *     second, independent numpy restatement: "parity unpinned" for the
- *     generator's bit stream.
+ *   - The INPUT GENERATOR (InitRandom) IS pinned against the reference itself:
+ *     its kernels (GPUSortingCUDA/UtilityKernels.cuh:53-117) are plain integer
+ *     arithmetic without inter-thread communication, so oracle/Makefile `_ref`
+ *     compiles that file from where it lies against the CUDA stand-in headers
+ *     in oracle/shim/ and runs it one emulated thread at a time
+ *     (oracle/_ref/libref_generator.so).  tests/test_oracle.py compares this
+ *     restatement with it directly, and tests/golden/ref_init_random.npz
+ *     (written by that library, tests/golden/make_ref_golden.py) carries the
+ *     reference-produced keys to boxes without the reference tree, where the
+ *     oracle and the HIP generator are checked against them.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).

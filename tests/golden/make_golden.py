@@ -3,9 +3,11 @@
 the reference's seeded input generator and of the sort's defined result.
 
 The reference (b0nes164/GPUSorting) ships no golden vectors for this path and
-cannot be built here (CUDA/PTX, D3D12, Unity), so these vectors do not come
-from the reference itself; they pin the C++ oracle (oracle/gs_oracle.cpp) and
-the HIP kernels against a second implementation written from the same spec:
+its sort kernels cannot be built here (CUDA/PTX, D3D12, Unity), so these vectors
+do not come from the reference itself (the generator's reference-produced
+vectors are in ref_init_random.npz, see make_ref_golden.py); they pin the C++
+oracle (oracle/gs_oracle.cpp) and the HIP kernels against a second
+implementation written from the same spec:
   generator  GPUSortingCUDA/UtilityKernels.cuh:29-33,53-117 (<<<256,256>>>)
   result     stable LSD radix sort == np.sort(kind="stable") on the sortable
              bits; descending == exact reverse (SortCommon.hlsl:594-597)

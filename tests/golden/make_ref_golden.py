@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_init_random.npz from the REFERENCE's OWN input generator.
+
+oracle/_ref/libref_generator.so (oracle/Makefile `_ref`) is the reference's
+GPUSortingCUDA/UtilityKernels.cuh:53-117 compiled for the CPU from where it lies under /root/reference and run
+one emulated CUDA thread at a time with the reference's launch shape <<<256,256>>>.  This script can therefore
+only run where /root/reference exists; its output is committed so that the oracle's restatement and the HIP
+generator are checked against reference-produced keys on boxes that have no reference tree.
+
+Per case (n, seed, andCount): crc32 of all keys, and the first / last 64 keys verbatim.
+Run:  make -C oracle _ref && python tests/golden/make_ref_golden.py
+"""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CASES = [(1, 1, 0), (2, 7, 0), (63, 2, 0), (7680, 7680, 0), (11111, 11111, 1), (15360, 15360, 0), (65535, 3, 2),
+         (65536, 10, 0), (65537, 10, 1), (200003, 77, 4), (1 << 20, 26, 0), (1 << 20, 27, 3), ((1 << 22) + 5, 28, 2)]
+
+
+def main():
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_generator.so"))
+    ref.ref_init_random.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    ref.ref_generator_source.restype = C.c_char_p
+    out = {"cases": np.array(CASES, dtype=np.int64), "source": np.array(ref.ref_generator_source().decode())}
+    for i, (n, seed, andc) in enumerate(CASES):
+        k = np.empty(n, np.uint32)
+        p = np.empty(n, np.uint32)
+        ref.ref_init_random(k.ctypes.data, p.ctypes.data, andc, seed, n)
+        assert np.array_equal(k, p)  # the pairs overload writes payload = key (UtilityKernels.cuh:114-115)
+        k2 = np.empty(n, np.uint32)
+        ref.ref_init_random(k2.ctypes.data, None, andc, seed, n)
+        assert np.array_equal(k, k2)
+        out[f"crc_{i}"] = np.uint32(zlib.crc32(k.tobytes()) & 0xFFFFFFFF)
+        out[f"head_{i}"] = k[:64].copy()
+        out[f"tail_{i}"] = k[-64:].copy()
+    path = os.path.join(HERE, "ref_init_random.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(CASES), "cases")
+
+
+if __name__ == "__main__":
+    main()

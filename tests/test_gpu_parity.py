@@ -63,6 +63,23 @@ def test_init_random_parity(gpu, oracle):
             np.testing.assert_array_equal(to_host(dv, rv.dtype), rv)
 
 
+def test_init_random_matches_reference_produced_vectors(gpu):
+    """The HIP generator against keys written by the reference's OWN InitRandom kernels (run on a CPU from the
+    reference sources: tests/golden/make_ref_golden.py -> tests/golden/ref_init_random.npz)."""
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_init_random.npz"))
+    for i, (n, seed, andc) in enumerate(g["cases"].tolist()):
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        dv = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, seed, andc, dv)
+        torch.cuda.synchronize()
+        k = to_host(dk, np.uint32)
+        assert crc(k) == int(g[f"crc_{i}"]), (n, seed, andc)
+        np.testing.assert_array_equal(k[:64], g[f"head_{i}"])
+        np.testing.assert_array_equal(k[-64:], g[f"tail_{i}"])
+        np.testing.assert_array_equal(to_host(dv, np.uint32), k)
+
+
 @pytest.mark.parametrize("kt", [0, 1, 2])
 def test_global_histogram_parity(gpu, oracle, kt):
     for n in (1, 3, 4, 5, 1023, 65536, 65539, (1 << 22) + 1):

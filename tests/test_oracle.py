@@ -138,3 +138,38 @@ def test_msd_splitters(oracle):
     skew[0] = 10**6
     fb = oracle.msd_splitters(skew, 4)
     assert fb[0] == 0 and fb[-1] == 256 and np.all(np.diff(fb.astype(np.int64)) >= 0)
+
+
+# ---- the generator pinned against the REFERENCE's own code -----------------------------------
+REF_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_init_random.npz")
+REF_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_generator.so")
+
+
+def test_generator_matches_reference_produced_vectors(oracle):
+    """tests/golden/ref_init_random.npz was written by the reference's InitRandom kernels themselves
+    (GPUSortingCUDA/UtilityKernels.cuh:53-117 compiled for the CPU, tests/golden/make_ref_golden.py)."""
+    g = np.load(REF_GOLDEN)
+    assert "UtilityKernels.cuh" in str(g["source"])
+    for i, (n, seed, andc) in enumerate(g["cases"].tolist()):
+        k = oracle.init_random(n, seed, andc)
+        assert zlib.crc32(k.tobytes()) & 0xFFFFFFFF == int(g[f"crc_{i}"]), (n, seed, andc)
+        np.testing.assert_array_equal(k[:64], g[f"head_{i}"])
+        np.testing.assert_array_equal(k[-64:], g[f"tail_{i}"])
+        kk, vv = oracle.init_random(n, seed, andc, 4)
+        np.testing.assert_array_equal(kk, k)
+        np.testing.assert_array_equal(vv, k)   # pairs overload: payload = key (:114-115)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LIB), reason="oracle/_ref is built only where /root/reference exists")
+def test_generator_matches_reference_code_run_here(oracle):
+    """oracle/_ref/libref_generator.so = the reference's kernels run one emulated thread at a time (oracle/Makefile)."""
+    import ctypes as C
+    ref = C.CDLL(REF_LIB)
+    ref.ref_init_random.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(5)
+    cases = [(1, 1, 0), (255, 9, 1), (65536, 10, 0), (65537, 11, 4), (300007, 12345, 2)]
+    cases += [(int(rng.integers(1, 400000)), int(rng.integers(1, 1 << 31)), int(rng.integers(0, 5))) for _ in range(12)]
+    for n, seed, andc in cases:
+        k = np.empty(n, np.uint32)
+        ref.ref_init_random(k.ctypes.data, None, andc, seed, n)
+        np.testing.assert_array_equal(oracle.init_random(n, seed, andc), k, err_msg=f"n={n} seed={seed} and={andc}")
