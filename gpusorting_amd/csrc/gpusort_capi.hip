@@ -100,6 +100,7 @@ struct gs_onesweep {
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int heavy;       // heavy-value position slices in keys-only sorts: 1 on (default), 0 off
+    uint32_t heavy_min_keys;  // ... from this many keys up (default 2^26; GPUSORT_HEAVY_MIN_LOG2, floor 2^22 in the kernel)
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -227,7 +228,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // bit 2: the heavy-value layout may be used (its counts are gathered in the LDS-atomic ranking path only)
     // (measured: it pays for keys-only sorts; with values the counting costs more than the balanced chains
     // gain, profiles/r01_entropy_*); GPUSORT_HEAVY=0 switches it off
-    const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && h->heavy != 0;  // compiled into the keys-only kernels only
+    // compiled into the keys-only kernels only; pays from 2^26 keys up (2^23..2^25: -3..-6 %, profiles/r01_heavy_threshold.txt)
+    const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && h->heavy != 0 && n >= h->heavy_min_keys;
     gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u), shape);
     if (st != GS_OK) return st;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
@@ -313,6 +315,11 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->small_path = 1;
     if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
     h->heavy = 1;
+    h->heavy_min_keys = 1u << 26;
+    if (const char* env = getenv("GPUSORT_HEAVY_MIN_LOG2")) {
+        const int lg = atoi(env);
+        if (lg >= 22 && lg <= 30) h->heavy_min_keys = 1u << lg;
+    }
     if (const char* env = getenv("GPUSORT_HEAVY")) h->heavy = atoi(env) ? 1 : 0;
     h->skip_passes = 1;
     if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;

@@ -22,7 +22,7 @@ def _run(lib, code):
     path = os.path.join(LIBDIR, lib)
     if not os.path.exists(path):
         pytest.fail(f"{lib} missing: run __graft_entry__.build()")
-    env = dict(os.environ, GPUSORT_LIB=path)
+    env = dict(os.environ, GPUSORT_LIB=path, GPUSORT_HEAVY_MIN_LOG2="22")  # heavy-value layout already at 2^23 keys
     out = subprocess.run([sys.executable, "-c", textwrap.dedent(code) % ROOT], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -513,9 +513,11 @@ def _heavy_inputs(oracle, n):
 
 
 @pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (4, 0, 0), (8, 0, 1), (0, 1, 1), (4, 2, 0)])
-def test_heavy_value_position_slices(gpu, oracle, vb, kt, order):
-    """A digit value holding > 1/4 of the keys: the next pass splits its run into position slices whose
-    bases come from counts gathered by the pass before (n >= 2^22 switches that layout on)."""
+def test_heavy_value_position_slices(gpu, oracle, vb, kt, order, monkeypatch):
+    """A digit value holding more than half of the keys: the next pass splits its run into position slices whose
+    bases come from counts gathered by the pass before.  The library switches that layout on from 2^26 keys
+    (where it pays); GPUSORT_HEAVY_MIN_LOG2 lowers the threshold to the kernel's floor for this test."""
+    monkeypatch.setenv("GPUSORT_HEAVY_MIN_LOG2", "22")
     n = (1 << 22) + 54321
     for name, keys in _heavy_inputs(oracle, n):
         vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
@@ -556,9 +558,11 @@ def _fuzz_keys(rng, oracle, n):
     return (u >> np.uint32(int(rng.integers(0, 31)))).astype(np.uint32)
 
 
-def test_fuzz_against_oracle(gpu, oracle):
-    """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, heavy layout),
-    distributions, key types, orders and value widths; every case bit-exact against the oracle."""
+def test_fuzz_against_oracle(gpu, oracle, monkeypatch):
+    """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, heavy layout —
+    its size threshold lowered to the kernel's floor), distributions, key types, orders and value widths;
+    every case bit-exact against the oracle."""
+    monkeypatch.setenv("GPUSORT_HEAVY_MIN_LOG2", "22")
     rng = np.random.default_rng(int(os.environ.get("GPUSORT_FUZZ_SEED", "20260925")))
     for case in range(int(os.environ.get("GPUSORT_FUZZ_CASES", "48"))):  # longer hunts: set the two variables
         top = (40000, 300000, 6 << 20)[case % 3]
