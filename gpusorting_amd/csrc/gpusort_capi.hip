@@ -69,7 +69,7 @@ struct Shape {
 const Shape g_shapes[] = {
     GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
     GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
-    GS_FULL(512, 16),   // mid sizes (n <= MID_KEYS): 8192-key tiles, shorter per-tile latency, more workgroups
+    GS_FULL(512, 16),   // mid sizes (n <= mid_keys): 8192-key tiles, shorter per-tile latency, more workgroups
 #ifndef GS_NO_TUNING_SHAPES
     GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
 #endif
@@ -86,8 +86,10 @@ using gs::SLAB_INFO;
 using gs::SLAB_STATUS;
 
 constexpr uint32_t MIN_TILE = 4096;  // smallest tile of any compiled shape (sizing of the slab)
-constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= MID_KEYS unless the caller picked a shape
-constexpr uint32_t MID_KEYS = 1u << 23;  // profiles/r01_mid_sweep_shapes.txt: 512x16 wins up to 2^23 keys (-20 % at 2^14..2^18)
+constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb) unless the caller picked a shape
+// profiles/r01_mid_sweep_shapes.txt: 512x16 wins up to 2^23 keys for keys-only sorts (-20 % at 2^14..2^18), up to 2^24
+// with 4-byte values and up to 2^25 with 8-byte values (whose big tile leaves one workgroup per CU)
+inline uint32_t mid_keys(uint32_t vb) { return vb == 8 ? (1u << 25) : vb == 4 ? (1u << 24) : (1u << 23); }
 
 }  // namespace
 
@@ -216,7 +218,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         // the single-tile kernel has no spin and cannot time out
         return GS_OK;
     }
-    const int shape = (h->shape_auto && n <= MID_KEYS) ? MID_SHAPE : h->shape;
+    const int shape = (h->shape_auto && n <= mid_keys(vb)) ? MID_SHAPE : h->shape;
     const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
