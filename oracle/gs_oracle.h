@@ -6,27 +6,36 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and there
  * only as the checker / the timed CPU baseline.
  *
- * PARITY PINNING STATUS
- *   - The reference (b0nes164/GPUSorting @ 2024_10_08) holds NO golden vector
- *     or known-answer test for this path.  Its SORT kernels
- *     (CUDA + PTX warp code, D3D12/HLSL, Unity C#) cannot be built or run in
- *     this image, so no reference-produced sort output exists to pin against.
- *   - The SORT RESULT is pinned by mathematical uniqueness: keys-only = the
- *     sorted multiset; pairs = the stable sort by key; descending = the exact
- *     reverse of the stable ascending result (reference
- *     GPUSortingD3D12/Shaders/SortCommon.hlsl:594-597,645-656).  It is
- *     cross-checked against two independent implementations (std::stable_sort
- *     here, numpy in tests/golden/make_golden.py).
- *   - The INPUT GENERATOR (InitRandom) IS pinned against the reference itself:
- *     its kernels (GPUSortingCUDA/UtilityKernels.cuh:53-117) are plain integer
- *     arithmetic without inter-thread communication, so oracle/Makefile `_ref`
- *     compiles that file from where it lies against the CUDA stand-in headers
- *     in oracle/shim/ and runs it one emulated thread at a time
- *     (oracle/_ref/libref_generator.so).  tests/test_oracle.py compares this
- *     restatement with it directly, and tests/golden/ref_init_random.npz
- *     (written by that library, tests/golden/make_ref_golden.py) carries the
- *     reference-produced keys to boxes without the reference tree, where the
- *     oracle and the HIP generator are checked against them.
+ * PARITY PINNING STATUS — pinned against the reference's own code, executed here
+ *   The reference (b0nes164/GPUSorting @ 2024_10_08) holds NO golden vector or
+ *   known-answer test for this path, and no toolchain for it
+ *   exists in this image (nvcc / DXC / Unity).  But the CUDA tree's path is four
+ *   kernels in one file and a generator in another, and a host compiler can
+ *   parse both, from where they lie under /root/reference, against stand-in
+ *   headers (oracle/shim/):
+ *   - INPUT GENERATOR: GPUSortingCUDA/UtilityKernels.cuh:53-117 has no
+ *     inter-thread communication; oracle/ref_generator.cpp runs it one emulated
+ *     thread at a time (oracle/_ref/libref_generator.so).
+ *   - SORT: GPUSortingCUDA/Sort/OneSweep.cu:44-600 (GlobalHistogram, Scan,
+ *     DigitBinningPassKeysOnly, DigitBinningPassPairs) runs under a small SIMT
+ *     emulator — fibers, 32-lane warp collectives, block barriers, blocks in
+ *     ticket order (oracle/shim/simt_emu.*, oracle/ref_onesweep.cpp ->
+ *     oracle/_ref/libref_onesweep.so).  Not the reference's own code in there:
+ *     the warp primitives of Utils.cuh (inline PTX; restated with the same
+ *     shuffle sequences) and the host launch sequence of
+ *     OneSweepDispatcher.cuh:301-363 (cudaMemset / <<< >>>; restated).
+ *   tests/test_oracle.py compares THIS restatement with both libraries directly
+ *   (generator bit stream; global histogram, the buffers after every pass,
+ *   sorted keys, payloads) where /root/reference exists, and
+ *   tests/golden/ref_init_random.npz / ref_onesweep.npz (written by those
+ *   libraries, tests/golden/make_ref_golden.py) carry the reference-produced
+ *   vectors to boxes without the reference tree, where the oracle AND the HIP
+ *   path are checked against them.
+ *   Not executable here, hence pinned only by their definition: the D3D12/Unity
+ *   extras — descending order and int/float key transforms
+ *   (GPUSortingD3D12/Shaders/SortCommon.hlsl:134-154,594-597,645-656); the
+ *   descending result is the exact reverse of the stable ascending one, the
+ *   transforms are the standard order-preserving bit flips.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).

@@ -9,6 +9,10 @@
  * intrinsics below are declarations with placeholder bodies and are never called.
  */
 #pragma once
+#ifdef GS_SIMT_EMU
+/* the kernels that DO communicate (OneSweep.cu) run under the SIMT emulator instead */
+#include "simt_emu.h"
+#else
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -42,3 +46,4 @@ template <class T, class U> inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (
 template <class T, class U, class W> inline T atomicCAS(T* p, U c, W v) { T o = *p; if (o == (T)c) *p = (T)v; return o; }
 template <class T, class U> inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T, class U> inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
+#endif /* GS_SIMT_EMU */

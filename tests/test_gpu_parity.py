@@ -80,6 +80,42 @@ def test_init_random_matches_reference_produced_vectors(gpu):
         np.testing.assert_array_equal(to_host(dv, np.uint32), k)
 
 
+def test_gpu_matches_reference_kernel_vectors(gpu):
+    """The HIP path against outputs of the reference's OWN OneSweep kernels (GPUSortingCUDA/Sort/OneSweep.cu run on
+    a CPU by the SIMT emulator of oracle/shim; tests/golden/ref_onesweep.npz): the global histogram, the key (and
+    payload) buffer after each of the four passes, and the sorted result of the complete sort."""
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_onesweep.npz"))
+    for i, (n, seed, andc, pairs) in enumerate(g["cases"].tolist()):
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, seed, andc)
+        dv = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if pairs else gpu.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+        assert crc(s.global_histogram(dk).astype(np.uint32)) == int(g[f"hist_{i}"]), (n, seed)
+        ck, cv = dk.clone(), (None if dv is None else dv.clone())
+        for p in range(4):                                  # pass by pass
+            ok = torch.zeros_like(ck)
+            ov = None if cv is None else torch.zeros_like(cv)
+            s.digit_pass(ck, ok, p, values_in=cv, values_out=ov)
+            s.check()
+            assert crc(to_host(ok, np.uint32)) == int(g[f"kcrc_{i}"][p]), (n, seed, p)
+            if pairs:
+                assert crc(to_host(ov, np.uint32)) == int(g[f"vcrc_{i}"][p]), (n, seed, p)
+            ck, cv = ok, ov
+        for small in (True, False):                         # the complete sort, both small-n routes
+            s.set_small_path(small)
+            fk, fv = dk.clone(), (None if dv is None else dv.clone())
+            s.sort(fk, fv)
+            s.check()
+            out = to_host(fk, np.uint32)
+            assert crc(out) == int(g[f"kcrc_{i}"][3]), (n, seed, small)
+            np.testing.assert_array_equal(out[:32], g[f"head_{i}"])
+            np.testing.assert_array_equal(out[-32:], g[f"tail_{i}"])
+            if pairs:
+                assert crc(to_host(fv, np.uint32)) == int(g[f"vcrc_{i}"][3]), (n, seed, small)
+        s.close()
+
+
 @pytest.mark.parametrize("kt", [0, 1, 2])
 def test_global_histogram_parity(gpu, oracle, kt):
     for n in (1, 3, 4, 5, 1023, 65536, 65539, (1 << 22) + 1):

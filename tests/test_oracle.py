@@ -173,3 +173,60 @@ def test_generator_matches_reference_code_run_here(oracle):
         k = np.empty(n, np.uint32)
         ref.ref_init_random(k.ctypes.data, None, andc, seed, n)
         np.testing.assert_array_equal(oracle.init_random(n, seed, andc), k, err_msg=f"n={n} seed={seed} and={andc}")
+
+
+# ---- the sort pinned against the REFERENCE's own kernels ---------------------------------------
+REF_SORT_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_onesweep.npz")
+REF_SORT_LIB = os.path.join(os.path.dirname(REF_LIB), "libref_onesweep.so")
+
+
+def _crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def test_oracle_matches_reference_kernel_vectors(oracle):
+    """tests/golden/ref_onesweep.npz was written by the reference's OneSweep kernels (GPUSortingCUDA/Sort/
+    OneSweep.cu) executed on a CPU by the SIMT emulator of oracle/shim: global histogram, the key (and payload)
+    buffer after every pass, the sorted result.  The oracle must reproduce every one of them."""
+    g = np.load(REF_SORT_GOLDEN)
+    assert "OneSweep.cu" in str(g["source"])
+    for i, (n, seed, andc, pairs) in enumerate(g["cases"].tolist()):
+        keys = oracle.init_random(n, seed, andc)
+        assert _crc(oracle.global_histogram(keys)) == int(g[f"hist_{i}"]), (n, seed)
+        cur_k, cur_v = keys.copy(), (np.arange(n, dtype=np.uint32) if pairs else None)
+        for p in range(4):
+            if pairs:
+                cur_k, cur_v = oracle.digit_pass(cur_k, 8 * p, vals=cur_v)
+                assert _crc(cur_v) == int(g[f"vcrc_{i}"][p]), (n, seed, p)
+            else:
+                cur_k = oracle.digit_pass(cur_k, 8 * p)
+            assert _crc(cur_k) == int(g[f"kcrc_{i}"][p]), (n, seed, p)
+        np.testing.assert_array_equal(cur_k[:32], g[f"head_{i}"])
+        np.testing.assert_array_equal(cur_k[-32:], g[f"tail_{i}"])
+        ref = oracle.std_sort(keys, 0, 0, np.arange(n, dtype=np.uint32) if pairs else None)
+        if pairs:
+            np.testing.assert_array_equal(ref[0], cur_k)
+            np.testing.assert_array_equal(ref[1], cur_v)   # the reference's passes ARE the stable sort
+        else:
+            np.testing.assert_array_equal(ref, cur_k)
+        np.testing.assert_array_equal(oracle.onesweep_sort(keys), cur_k)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SORT_LIB), reason="oracle/_ref is built only where /root/reference exists")
+def test_oracle_matches_reference_kernels_run_here(oracle):
+    import ctypes as C
+    ref = C.CDLL(REF_SORT_LIB)
+    ref.ref_onesweep_sort_keys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    ref.ref_onesweep_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    for n in [1, 33, 7680, 15361] + [int(rng.integers(2, 30000)) for _ in range(4)]:
+        andc = int(rng.integers(0, 5))
+        keys = oracle.init_random(n, n + 3, andc)
+        k = keys.copy()
+        ref.ref_onesweep_sort_keys(k.ctypes.data, n, None, None)
+        np.testing.assert_array_equal(k, oracle.std_sort(keys), err_msg=f"keys n={n}")
+        k, v = keys.copy(), np.arange(n, dtype=np.uint32)
+        ref.ref_onesweep_sort_pairs(k.ctypes.data, v.ctypes.data, n, None, None, None)
+        rk, rv = oracle.std_sort(keys, 0, 0, np.arange(n, dtype=np.uint32))
+        np.testing.assert_array_equal(k, rk, err_msg=f"pairs n={n}")
+        np.testing.assert_array_equal(v, rv, err_msg=f"payload n={n}")
