@@ -86,6 +86,7 @@ static inline uint32_t WarpReduceSum(uint32_t v) {
 
 // 3) the reference's kernels
 #include "Sort/OneSweep.cu"
+#include "UtilityKernels.cuh"  // Validate (:402-479): the reference's pass criterion
 
 namespace {
 inline uint32_t div_round_up(uint32_t x, uint32_t y) { return (x + y - 1) / y; }  // OneSweepDispatcher.cuh:296-299
@@ -137,6 +138,15 @@ void ref_onesweep_sort_keys(uint32_t* keys, uint32_t size, uint32_t* out_global_
 void ref_onesweep_sort_pairs(uint32_t* keys, uint32_t* payload, uint32_t size, uint32_t* out_global_hist,
                              uint32_t* out_after_pass, uint32_t* out_payload_after_pass) {
     run(keys, payload, size, out_global_hist, out_after_pass, out_payload_after_pass);
+}
+/* OneSweepDispatcher.cuh:365-391 (DispatchValidateKeys / DispatchValidatePairs): Validate<<<ceil(n/4096), 256>>>;
+ * returns the reference's error count (the dispatcher reports success iff it is 0) */
+uint32_t ref_validate(uint32_t* keys, uint32_t* payload_or_null, uint32_t size) {
+    uint32_t err = 0;
+    const uint32_t blocks = div_round_up(size, 4096);
+    if (payload_or_null) gs_emu::launch(blocks, 256, [&] { Validate(keys, payload_or_null, &err, size); });
+    else gs_emu::launch(blocks, 256, [&] { Validate(keys, &err, size); });
+    return err;
 }
 const char* ref_onesweep_source() {
     return "GPUSortingCUDA/Sort/OneSweep.cu:44-600 executed on the CPU by oracle/shim/simt_emu (warp primitives of "

@@ -59,6 +59,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body);
 
 inline void __syncthreads() { gs_emu::barrier(); }
 inline void __threadfence() {}
+inline void __syncwarp(unsigned = 0xffffffffu) {}  /* never reached by the kernels that are run */
 inline unsigned __activemask() { return (unsigned)gs_emu::collective(gs_emu::OP_ACTIVEMASK, 0, 0, 0); }
 inline unsigned __ballot_sync(unsigned mask, int pred) {
     return (unsigned)gs_emu::collective(gs_emu::OP_BALLOT, mask, pred ? 1u : 0u, 0);

@@ -49,7 +49,8 @@ if __name__ == "__main__":
 
 # ---------------------------------------------------------------------------------------------------
 # Part 2: the reference's OneSweep KERNELS (GPUSortingCUDA/Sort/OneSweep.cu) executed by the SIMT emulator
-# (oracle/_ref/libref_onesweep.so, oracle/ref_onesweep.cpp).  Per case: crc32 of the global histogram, of the
+# (oracle/_ref/libref_onesweep.so, oracle/ref_onesweep.cpp).  Per case: the error count of the reference's
+# Validate kernel on the unsorted input (and the check that it is 0 on the output), crc32 of the global histogram, of the
 # key buffer after each of the four passes (the fourth = the sorted result) and, for pairs, of the payload
 # buffer after each pass; plus the first/last 32 sorted keys verbatim.  Inputs come from the reference's own
 # generator (part 1); payload = original index, which exposes stability.
@@ -67,11 +68,15 @@ def sort_goldens():
     ref.ref_onesweep_sort_keys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     ref.ref_onesweep_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     ref.ref_onesweep_source.restype = C.c_char_p
+    ref.ref_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    ref.ref_validate.restype = C.c_uint32
     crc = lambda a: np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
     out = {"cases": np.array(SORT_CASES, dtype=np.int64), "source": np.array(ref.ref_onesweep_source().decode())}
     for i, (n, seed, andc, pairs) in enumerate(SORT_CASES):
         k = np.empty(n, np.uint32)
         gen.ref_init_random(k.ctypes.data, None, andc, seed, n)
+        # the reference's Validate kernel (UtilityKernels.cuh:402-479) on the UNSORTED input: its error count
+        out[f"verr_{i}"] = np.uint32(ref.ref_validate(k.ctypes.data, None, n))
         gh = np.zeros(1024, np.uint32)
         ap = np.zeros(4 * n, np.uint32)
         if pairs:
@@ -83,6 +88,7 @@ def sort_goldens():
         else:
             ref.ref_onesweep_sort_keys(k.ctypes.data, n, gh.ctypes.data, ap.ctypes.data)
         assert np.array_equal(k, ap[3 * n:]) and bool(np.all(k[1:] >= k[:-1]))
+        assert ref.ref_validate(k.ctypes.data, None, n) == 0  # the reference's own pass criterion on its own output
         out[f"hist_{i}"] = crc(gh)
         out[f"kcrc_{i}"] = np.array([crc(ap[p * n:(p + 1) * n]) for p in range(4)], dtype=np.uint32)
         out[f"head_{i}"] = k[:32].copy()

@@ -91,6 +91,7 @@ def test_gpu_matches_reference_kernel_vectors(gpu):
         gpu.init_random(dk, seed, andc)
         dv = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
         s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if pairs else gpu.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+        assert gpu.validate(dk) == int(g[f"verr_{i}"]), (n, seed)   # the reference's Validate on the unsorted input
         assert crc(s.global_histogram(dk).astype(np.uint32)) == int(g[f"hist_{i}"]), (n, seed)
         ck, cv = dk.clone(), (None if dv is None else dv.clone())
         for p in range(4):                                  # pass by pass

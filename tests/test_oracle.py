@@ -192,6 +192,7 @@ def test_oracle_matches_reference_kernel_vectors(oracle):
     assert "OneSweep.cu" in str(g["source"])
     for i, (n, seed, andc, pairs) in enumerate(g["cases"].tolist()):
         keys = oracle.init_random(n, seed, andc)
+        assert oracle.validate(keys) == int(g[f"verr_{i}"]), (n, seed)   # the reference's Validate on the unsorted input
         assert _crc(oracle.global_histogram(keys)) == int(g[f"hist_{i}"]), (n, seed)
         cur_k, cur_v = keys.copy(), (np.arange(n, dtype=np.uint32) if pairs else None)
         for p in range(4):
@@ -218,7 +219,14 @@ def test_oracle_matches_reference_kernels_run_here(oracle):
     ref = C.CDLL(REF_SORT_LIB)
     ref.ref_onesweep_sort_keys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     ref.ref_onesweep_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    ref.ref_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    ref.ref_validate.restype = C.c_uint32
     rng = np.random.default_rng(11)
+    for n in (2, 4096, 4097, 8192, 12289):   # the pass criterion, incl. its partition boundaries
+        k = oracle.init_random(n, n, 0)
+        assert ref.ref_validate(k.ctypes.data, None, n) == oracle.validate(k)
+        v = k.copy()
+        assert ref.ref_validate(k.ctypes.data, v.ctypes.data, n) == oracle.validate(k, 0, 0, v)
     for n in [1, 33, 7680, 15361] + [int(rng.integers(2, 30000)) for _ in range(4)]:
         andc = int(rng.integers(0, 5))
         keys = oracle.init_random(n, n + 3, andc)
