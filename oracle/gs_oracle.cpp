@@ -1,7 +1,8 @@
 /*
  * gs_oracle.cpp — CPU restatement of the reference's OneSweep path.
  * TEST INFRASTRUCTURE ONLY — see gs_oracle.h for the rules and the parity
- * pinning status ("parity unpinned" for the generator's bit stream).
+ * pinning status (pinned against the reference's own generator and OneSweep
+ * kernels executed on the CPU: oracle/ref_generator.cpp, oracle/ref_onesweep.cpp).
  * Citations are relative to /root/reference.
  */
 #include "gs_oracle.h"

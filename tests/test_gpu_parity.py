@@ -419,7 +419,7 @@ def test_single_tile_path_and_tiled_path_agree(gpu, oracle, small_path, vb, kt, 
 
 @pytest.mark.parametrize("n,vb", [(5000, 0), ((1 << 20) + 3, 0), ((1 << 18) + 1, 4)])
 def test_sort_is_hip_graph_capturable(gpu, oracle, n, vb):
-    """A sort is one memset + six kernels on the caller's stream and nothing synchronous, so it can be
+    """A sort is six kernels on the caller's stream and nothing synchronous, so it can be
     captured once into a HIP graph and replayed on new data in the same buffers."""
     import torch
     s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
