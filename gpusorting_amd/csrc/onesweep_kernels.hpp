@@ -161,6 +161,9 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_DESC % 4 == 0, "r
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif
+#ifndef GS_HIST_SKEW_LANES
+#define GS_HIST_SKEW_LANES 8  // lanes sharing the first lane's bin that switch a byte's counting to wave-aggregated adds
+#endif
 #ifndef GS_HIST_UNROLL
 #define GS_HIST_UNROLL 4
 #endif
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                     // per lane.  Cheap probe on the first key: do >= 8 lanes share the first lane's bin?
                     const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin[0]);
                     const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
-                    if (pc >= 8) {
+                    if (pc >= GS_HIST_SKEW_LANES) {
                         skew_mode |= 1u << q;
                         if (pc >= 24 || sticky[q] == 0xffffffffu) sticky[q] = b0;  // (re)learn the dominant bin
                     }
