@@ -15,7 +15,10 @@ gpusorting_amd/lib/libgpusort_fault_nofallback.so: $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -DGS_EXP=8 -DGS_FALLBACK=0 -DGS_SPIN_LIMIT=4096 -DGS_NO_TUNING_SHAPES $(SRC) -o $@
 oracle:
 	$(MAKE) -C oracle
-tools: build/gpusorting_main build/rocprim_compare
+tools: build/gpusorting_main build/gpusorting_d3d12_main build/rocprim_compare
+build/gpusorting_d3d12_main: tools/gpusorting_d3d12_main.cpp include/gpusort/GPUSortBase.hpp $(LIB)
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Iinclude tools/gpusorting_d3d12_main.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
 build/gpusorting_main: tools/gpusorting_main.cpp include/gpusort/OneSweepDispatcher.hpp $(LIB)
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Iinclude tools/gpusorting_main.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
