@@ -613,3 +613,24 @@ def test_fuzz_against_oracle(gpu, oracle, monkeypatch):
         np.testing.assert_array_equal(ok, rk, err_msg=f"case {case}: n={n} kt={kt} order={order} vb={vb}")
         if vals is not None:
             np.testing.assert_array_equal(ov, rv, err_msg=f"case {case} values: n={n} kt={kt} order={order} vb={vb}")
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_unity_light_test_matrix(gpu, oracle, pairs):
+    """Unity's light tests (GPUSortingUnity/Tests/TestBase.cs:238-264 and the pairs twin): every power of two
+    from 2 to 65536 x {ascending, descending} x {uint, int, float} keys, seed = size — 96 sorts, each bit-exact."""
+    passed = 0
+    for lg in range(1, 17):
+        n = 1 << lg
+        keys = oracle.init_random(n, n, 0)
+        vals = np.arange(n, dtype=np.uint32) if pairs else None
+        for kt in (0, 1, 2):
+            for order in (0, 1):
+                ok, ov = _gpu_sort(gpu, keys, kt, order, vals)
+                ref = oracle.std_sort(keys, kt, order, vals)
+                rk, rv = (ref, None) if vals is None else ref
+                np.testing.assert_array_equal(ok, rk, err_msg=f"n={n} kt={kt} order={order}")
+                if pairs:
+                    np.testing.assert_array_equal(ov, rv, err_msg=f"values n={n} kt={kt} order={order}")
+                passed += 1
+    assert passed == 96
