@@ -54,13 +54,15 @@ def test_2pow28_properties(gpu, pairs):
     s.close()
 
 
-def test_maximum_size_2pow30_minus_1(gpu):
-    """Largest n the API accepts (30-bit tile-descriptor payload): 4 GiB of keys.  Properties only:
-    the reference's own pass criterion (no inversion) and all four digit histograms preserved."""
+@pytest.mark.parametrize("andc", [0, 4])
+def test_maximum_size_2pow30_minus_1(gpu, andc):
+    """Largest n the API accepts (30-bit tile-descriptor payload): 4 GiB of keys, uniform and at entropy preset 5
+    (heavy-value slices with the largest possible counts).  Properties only: the reference's own pass criterion
+    (no inversion) and all four digit histograms preserved."""
     import torch
     n = (1 << 30) - 1
     dk = torch.empty(n + 1, dtype=torch.int32, device="cuda")[:n]
-    gpu.init_random(dk, 30, 0, n=n)
+    gpu.init_random(dk, 30, andc, n=n)
     s = gpu.OneSweep(n)
     h_before = s.global_histogram(dk, n)
     assert int(h_before[0].sum()) == n
