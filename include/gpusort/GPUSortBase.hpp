@@ -135,6 +135,12 @@ protected:
         return ms * 1e-3;
     }
 
+    void Banner(const char* what) {  // "Beginning <sort><config><what>"
+        printf("Beginning %s", k_sortName);
+        PrintSortingConfig(k_sortingConfig);
+        printf("%s", what);
+    }
+
     GPUSortBase(const char* sortName, GPUSorting::GPUSortingConfig cfg, uint32_t maxReadBack)
         : k_sortName(sortName), k_sortingConfig(cfg), k_maxReadBack(maxReadBack) {
         m_partitionSize = gs_onesweep_partition_size(pairs() ? GS_MODE_PAIRS : GS_MODE_KEYS_ONLY, pairs() ? 4u : 0u);
@@ -172,69 +178,47 @@ public:
 
     // GPUSortBase.h:206-235
     void BatchTiming(uint32_t inputSize, uint32_t batchSize, uint32_t seed, GPUSorting::ENTROPY_PRESET entropyPreset) {
+        static const float bitsOfEntropy[5] = {1.0f, .811f, .544f, .337f, .201f};  // Thearling-Smith presets
         UpdateSize(inputSize);
-        const float entLookup[5] = {1.0f, .811f, .544f, .337f, .201f};
-        printf("Beginning ");
-        printf("%s", k_sortName);
-        PrintSortingConfig(k_sortingConfig);
-        printf("batch timing test at:\n");
-        printf("Size: %u\n", inputSize);
-        printf("Entropy: %f bits\n", entLookup[entropyPreset]);
-        printf("Test size: %u\n", batchSize);
+        Banner("batch timing test at:\n");
+        printf("Size: %u\nEntropy: %f bits\nTest size: %u\n", inputSize, bitsOfEntropy[entropyPreset], batchSize);
         double totalTime = 0.0;
-        for (uint32_t i = 0; i <= batchSize; ++i) {
-            const double t = TimeSort(i + seed, entropyPreset);
-            if (i) totalTime += t;
+        (void)TimeSort(seed, entropyPreset);  // iteration 0 warms up and is not counted
+        printf(".");
+        for (uint32_t i = 1; i <= batchSize; ++i) {
+            totalTime += TimeSort(i + seed, entropyPreset);
             if ((i & 7) == 0) printf(".");
         }
-        printf("\n");
-        printf("Total time elapsed: %f\n", totalTime);
+        printf("\nTotal time elapsed: %f\n", totalTime);
         printf("Estimated speed at %u 32-bit elements: %E keys/sec\n\n", inputSize, inputSize / totalTime * batchSize);
     }
 
     // GPUSortBase.h:237-275
     virtual bool TestAll() {
-        printf("Beginning ");
-        printf("%s", k_sortName);
-        PrintSortingConfig(k_sortingConfig);
-        printf("test all. \n");
-        uint32_t sortPayloadTestsPassed = 0;
-        const uint32_t testEnd = m_partitionSize * 2 + 1;
-        for (uint32_t i = m_partitionSize; i < testEnd; ++i) {
-            sortPayloadTestsPassed += ValidateSort(i, i);
-            if (!(i & 127)) printf(".");
+        Banner("test all. \n");
+        // every remainder class of a partition: sizes P .. 2P with seed = size ...
+        uint32_t passed = 0;
+        for (uint32_t size = m_partitionSize; size <= 2 * m_partitionSize; ++size) {
+            passed += ValidateSort(size, size) ? 1u : 0u;
+            if ((size & 127) == 0) printf(".");
         }
-        printf("\n");
-        printf("%u / %u passed. \n", sortPayloadTestsPassed, m_partitionSize + 1);
+        printf("\n%u / %u passed. \n", passed, m_partitionSize + 1);
+        // ... then three large sizes with the reference's seeds
         printf("Beginning large size tests\n");
-        sortPayloadTestsPassed += ValidateSort(1 << 21, 5);
-        sortPayloadTestsPassed += ValidateSort(1 << 22, 7);
-        sortPayloadTestsPassed += ValidateSort(1 << 23, 11);
-        const uint32_t testsExpected = m_partitionSize + 1 + 3;
-        if (sortPayloadTestsPassed == testsExpected) {
-            printf("%u / %u  All tests passed. \n\n", testsExpected, testsExpected);
-            return true;
-        }
-        printf("%u / %u  Test failed. \n\n", sortPayloadTestsPassed, testsExpected);
-        return false;
+        static const uint32_t large[3][2] = {{1u << 21, 5}, {1u << 22, 7}, {1u << 23, 11}};
+        for (const auto& t : large) passed += ValidateSort(t[0], t[1]) ? 1u : 0u;
+        const uint32_t expected = m_partitionSize + 1 + 3;
+        const bool all = passed == expected;
+        printf("%u / %u  %s \n\n", all ? expected : passed, expected, all ? "All tests passed." : "Test failed.");
+        return all;
     }
 
-    // GPUSortBase.h:547-583
-    static void PrintSortingConfig(const GPUSorting::GPUSortingConfig& sortingConfig) {
-        switch (sortingConfig.sortingKeyType) {
-        case GPUSorting::KEY_UINT32: printf("keys uint32 "); break;
-        case GPUSorting::KEY_INT32: printf("keys int32 "); break;
-        case GPUSorting::KEY_FLOAT32: printf("keys float32 "); break;
-        }
-        if (sortingConfig.sortingMode == GPUSorting::MODE_PAIRS) {
-            switch (sortingConfig.sortingPayloadType) {
-            case GPUSorting::PAYLOAD_UINT32: printf("payload uint32 "); break;
-            case GPUSorting::PAYLOAD_INT32: printf("payload int32 "); break;
-            case GPUSorting::PAYLOAD_FLOAT32: printf("payload float32 "); break;
-            }
-        }
-        if (sortingConfig.sortingOrder == GPUSorting::ORDER_ASCENDING) printf("ascending ");
-        else printf("descending ");
+    // same words as GPUSortBase.h:547-583: "keys <type> [payload <type> ]<order> "
+    static void PrintSortingConfig(const GPUSorting::GPUSortingConfig& cfg) {
+        static const char* const typeName[3] = {"uint32", "int32", "float32"};
+        printf("keys %s ", typeName[cfg.sortingKeyType]);
+        if (cfg.sortingMode == GPUSorting::MODE_PAIRS) printf("payload %s ", typeName[cfg.sortingPayloadType]);
+        printf("%s ", cfg.sortingOrder == GPUSorting::ORDER_ASCENDING ? "ascending" : "descending");
     }
 };
 
