@@ -634,3 +634,32 @@ def test_unity_light_test_matrix(gpu, oracle, pairs):
                     np.testing.assert_array_equal(ov, rv, err_msg=f"values n={n} kt={kt} order={order}")
                 passed += 1
     assert passed == 96
+
+
+_REF_SORT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_onesweep.so")
+
+
+@pytest.mark.skipif(not os.path.exists(_REF_SORT_LIB), reason="oracle/_ref is built only where /root/reference exists")
+def test_gpu_equals_reference_kernels_run_live(gpu):
+    """Head to head on this box: the reference's own OneSweep kernels (oracle/_ref: OneSweep.cu under the SIMT
+    emulator, on the CPU) and the HIP path sort the SAME device-generated input; keys and payloads must be equal."""
+    import ctypes as C
+    import torch
+    ref = C.CDLL(_REF_SORT_LIB)
+    ref.ref_onesweep_sort_keys.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    ref.ref_onesweep_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    for n in [7680, 15361] + [int(rng.integers(2, 40000)) for _ in range(5)]:
+        andc = int(rng.integers(0, 5))
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, n + 1, andc)
+        dv = torch.arange(n, dtype=torch.int32, device="cuda")
+        hk = to_host(dk, np.uint32).copy()
+        hv = np.arange(n, dtype=np.uint32)
+        ref.ref_onesweep_sort_pairs(hk.ctypes.data, hv.ctypes.data, n, None, None, None)   # the reference, on the CPU
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS, value_bytes=4)
+        s.sort(dk, dv)                                                                       # this library, on the GPU
+        s.check()
+        np.testing.assert_array_equal(to_host(dk, np.uint32), hk, err_msg=f"keys n={n} preset={andc + 1}")
+        np.testing.assert_array_equal(to_host(dv, np.uint32), hv, err_msg=f"payloads n={n} preset={andc + 1}")
+        s.close()
