@@ -47,6 +47,8 @@ _PROTOS = [
     ("gs_init_random", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     ("gs_validate", _int, [_vp, _vp, _u32, _u32, _int, _int, C.POINTER(_u32), _vp]),
     ("gs_msd_splitters", _int, [C.POINTER(C.c_uint64), _u32, C.POINTER(_u32)]),
+    ("gs_msd_splitters_n", _int, [C.POINTER(C.c_uint64), _u32, _u32, C.POINTER(_u32)]),
+    ("gs_onesweep_msd_fine_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
 ]
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
 

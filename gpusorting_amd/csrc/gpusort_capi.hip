@@ -640,21 +640,46 @@ gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_byt
     return ret;
 }
 
-gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t* first_bin) {
-    if (!hist256 || !first_bin || world == 0 || world > 256) return GS_ERR_ARG;
+gs_status gs_msd_splitters_n(const uint64_t* hist, uint32_t nbins, uint32_t world, uint32_t* first_bin) {
+    if (!hist || !first_bin || world == 0 || nbins == 0 || world > nbins) return GS_ERR_ARG;
     uint64_t total = 0;
-    for (int b = 0; b < 256; ++b) total += hist256[b];
-    // Rank r starts at the first top-byte bin whose exclusive prefix reaches
-    // ceil(r * total / world): equal-count buckets at bin granularity.
+    for (uint32_t b = 0; b < nbins; ++b) total += hist[b];
+    // Rank r starts at the first bin whose exclusive prefix reaches ceil(r * total / world):
+    // equal-count buckets at bin granularity.
     first_bin[0] = 0;
     uint64_t excl = 0;
     uint32_t b = 0;
     for (uint32_t r = 1; r < world; ++r) {
         const uint64_t target = (total * r + world - 1) / world;
-        while (b < 256 && excl < target) excl += hist256[b++];
+        while (b < nbins && excl < target) excl += hist[b++];
         first_bin[r] = b;
     }
-    first_bin[world] = 256;
+    first_bin[world] = nbins;
+    return GS_OK;
+}
+
+gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t* first_bin) {
+    if (world > 256) return GS_ERR_ARG;
+    return gs_msd_splitters_n(hist256, 256, world, first_bin);
+}
+
+// 12-bit prefix histogram of a shard: (top byte, top nibble of the byte below) = the joint histogram the sort's
+// own GlobalHistogram kernel counts for the last pass (chain = group of the previous digit), bin = d3*16 + (d2>>4).
+gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt,
+                                         uint32_t* h_hist4096, void* stream) {
+    static_assert(gs::NCH == 16, "the fine MSD histogram is the 16-chain joint histogram");
+    if (!h || !d_keys || !h_hist4096 || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n == 0 || n > h->max_keys || n > GS_MAX_KEYS) return GS_ERR_SIZE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PassPlan plan;
+    gs_status st = prologue(h, d_keys, n, kt, s, 2, 2, &plan);  // bytes 2 and 3: row 1 = H(d3, group of d2)
+    if (st != GS_OK) return st;
+    const size_t words = 2 * (size_t)gs::NCH * gs::RADIX;
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
+    GS_HIP(hipStreamSynchronize(s));
+    for (uint32_t d = 0; d < gs::RADIX; ++d)
+        for (uint32_t x = 0; x < gs::NCH; ++x) h_hist4096[d * gs::NCH + x] = h->pinned[gs::hist_index(1, d, x)];
     return GS_OK;
 }
 

@@ -201,6 +201,15 @@ class OneSweep:
               "gs_onesweep_msd_prepare")
         return np.frombuffer(out, dtype=np.uint32).copy()
 
+    def msd_fine_histogram(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
+        """4096-bin histogram of the 12-bit key prefix (top byte, top nibble of the next byte); synchronous."""
+        _require_cuda(keys, "keys")
+        n = keys.numel() if n is None else int(n)
+        out = (C.c_uint32 * 4096)()
+        check(self._lib.gs_onesweep_msd_fine_histogram(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
+              "gs_onesweep_msd_fine_histogram")
+        return np.frombuffer(out, dtype=np.uint32).copy()
+
     def msd_partition(self, keys_in: torch.Tensor, keys_out: torch.Tensor, n: int | None = None,
                       values_in: torch.Tensor | None = None, values_out: torch.Tensor | None = None) -> None:
         n = keys_in.numel() if n is None else int(n)

@@ -7,8 +7,10 @@ BASELINE.json configs[3].  One process per GPU, ``torch.distributed`` (backend
   1. top-byte histogram of the local shard (the GlobalHistogram kernel's row 3)
   2. ONE small all_gather of the 256-bin histograms -> every rank knows every
      (source, bin) count, hence the global histogram, the splitters
-     (``gs_msd_splitters``: equal-count buckets at top-byte granularity) and all
-     send/receive counts without a second exchange
+     (``gs_msd_splitters_n``: equal-count buckets at top-byte granularity) and all
+     send/receive counts without a second exchange.  If a bucket would not fit
+     its rank (skewed keys), the split is redone at 12-bit prefix granularity:
+     4096-bin histograms, shard ordered by its top two bytes
   3. a stable DigitBinningPass on the top byte groups the shard by destination
   4. ``all_to_all_single`` with split sizes (RCCL AllToAllv; point-to-point on
      all xGMI links at once) moves every key to its owner
@@ -31,11 +33,11 @@ import torch.distributed as dist
 from . import _lib
 
 
-def msd_splitters(hist256: np.ndarray, world: int) -> np.ndarray:
-    """first_bin[r] = first top-byte value rank r owns; host-side C-ABI call."""
-    h = np.ascontiguousarray(hist256, dtype=np.uint64)
+def msd_splitters(hist: np.ndarray, world: int) -> np.ndarray:
+    """first_bin[r] = first bin (top byte, or 12-bit prefix for a 4096-bin histogram) rank r owns; host-side C-ABI call."""
+    h = np.ascontiguousarray(hist, dtype=np.uint64)
     fb = (C.c_uint32 * (world + 1))()
-    _lib.check(_lib.load().gs_msd_splitters(h.ctypes.data_as(C.POINTER(C.c_uint64)), world, fb), "gs_msd_splitters")
+    _lib.check(_lib.load().gs_msd_splitters_n(h.ctypes.data_as(C.POINTER(C.c_uint64)), h.size, world, fb), "gs_msd_splitters_n")
     return np.frombuffer(fb, dtype=np.uint32).copy()
 
 
@@ -62,6 +64,15 @@ class HipLocalEngine:
             self.sorter.msd_partition(keys, out, n=n, values_in=values, values_out=values_out)
         else:
             self.sorter.digit_pass(keys, out, 3, n=n, values_in=values, values_out=values_out)
+
+    def fine_histogram(self, keys, n) -> np.ndarray:
+        return self.sorter.msd_fine_histogram(keys, n).astype(np.int64)
+
+    def partition_by_top12(self, keys, out, tmp, n, values=None, values_out=None, values_tmp=None):
+        """Stable order by the top two bytes (pass 2 into tmp, pass 3 into out): contiguous in the 12-bit prefix."""
+        self._prepared = None
+        self.sorter.digit_pass(keys, tmp, 2, n=n, values_in=values, values_out=values_tmp)
+        self.sorter.digit_pass(tmp, out, 3, n=n, values_in=values_tmp, values_out=values_out)
 
     def sort(self, keys, n, values=None):
         self.sorter.sort(keys, values, n=n)
@@ -90,7 +101,9 @@ class ShardedOneSweep:
             self._part_v = torch.empty(self.shard_keys, dtype=dt, device=dev)
             self._recv_v = torch.empty(self.capacity, dtype=dt, device=dev)
         self._gather = torch.empty(self.world * 256, dtype=torch.int64, device=dev)
+        self._gather_fine = None  # world x 4096, allocated on first use (skewed shards only)
         self.last_counts = None
+        self.last_split = None    # "top byte" or "12-bit prefix"
         # gloo cannot move device memory: with that backend and a GPU engine the two collectives are staged
         # through host tensors (test configuration: several ranks sharing one GPU; the product backend is RCCL)
         self._host_staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
@@ -142,18 +155,37 @@ class ShardedOneSweep:
         local = torch.from_numpy(eng.top_byte_histogram(keys, n)).to(self._gather.device)
         self._all_gather(self._gather, local)
         table = self._gather.cpu().numpy().reshape(W, 256)          # [source, top byte]
-        first_bin = msd_splitters(table.sum(axis=0).astype(np.uint64), W)
-        csum = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(table, axis=1)], axis=1)
-        per_dest = csum[:, first_bin[1:]] - csum[:, first_bin[:-1]]  # [source, dest]
+
+        def split(tab):
+            first_bin = msd_splitters(tab.sum(axis=0).astype(np.uint64), W)
+            csum = np.concatenate([np.zeros((W, 1), np.int64), np.cumsum(tab, axis=1)], axis=1)
+            return csum[:, first_bin[1:]] - csum[:, first_bin[:-1]]  # [source, dest]
+
+        per_dest = split(table)
+        fine = int(per_dest.sum(axis=0).max()) > self.capacity       # same table on every rank: same decision
+        if fine:
+            # Some rank's top-byte bucket would not fit (skewed keys: SURVEY.md §8e).  Split at the 12-bit prefix
+            # instead: 4096-bin histograms, and the shard ordered by its top TWO bytes so that every prefix
+            # range is contiguous (one more partition pass; only on this path).
+            if self._gather_fine is None:
+                self._gather_fine = torch.empty(W * 4096, dtype=torch.int64, device=self._gather.device)
+            local = torch.from_numpy(eng.fine_histogram(keys, n)).to(self._gather.device)
+            self._all_gather(self._gather_fine, local)
+            per_dest = split(self._gather_fine.cpu().numpy().reshape(W, 4096))
+        self.last_split = "12-bit prefix" if fine else "top byte"
         send = per_dest[self.rank].tolist()
         recv = per_dest[:, self.rank].tolist()
         n_recv = int(sum(recv))
         self.last_counts = (send, recv)
-        if n_recv > self.capacity:
-            raise RuntimeError(f"rank {self.rank}: bucket of {n_recv} keys exceeds capacity {self.capacity}; "
-                               "input too skewed for a top-byte MSD split (raise slack)")
+        if int(per_dest.sum(axis=0).max()) > self.capacity:          # every rank raises together
+            raise RuntimeError(f"rank {self.rank}: a bucket of {int(per_dest.sum(axis=0).max())} keys exceeds capacity "
+                               f"{self.capacity} even at 12-bit prefix granularity (raise slack)")
         # 3: group by destination (stable)
-        eng.partition_by_top_byte(keys, self._part, n, values, self._part_v)
+        if fine:
+            eng.partition_by_top12(keys, self._part, self._recv[:n], n, values, self._part_v,
+                                   None if values is None else self._recv_v[:n])
+        else:
+            eng.partition_by_top_byte(keys, self._part, n, values, self._part_v)
         # 4: bucket exchange
         self._all_to_all(self._recv[:n_recv], self._part[:n], recv, send)
         if values is not None:

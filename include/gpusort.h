@@ -183,6 +183,13 @@ gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_byt
  * From the all-reduced top-byte histogram pick the first top-byte bin each of
  * `world` ranks owns: first_bin[0] = 0 ... first_bin[world] = 256. */
 gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t* first_bin);
+/* The same over any number of bins (first_bin[world] = nbins). */
+gs_status gs_msd_splitters_n(const uint64_t* hist, uint32_t nbins, uint32_t world, uint32_t* first_bin);
+/* Finer split for skewed shards (top-byte buckets can overflow): the 4096-bin histogram of the
+ * 12-bit key prefix, bin = top_byte * 16 + (next byte >> 4), read back to the host (synchronous).  A shard sorted
+ * by its top two bytes (two gs_onesweep_digit_pass calls: pass 2, then pass 3) is contiguous in that prefix. */
+gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type key_type,
+                                         uint32_t* h_hist4096, void* stream);
 
 #ifdef __cplusplus
 }

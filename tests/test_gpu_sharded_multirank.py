@@ -25,14 +25,24 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     from gpusorting_amd.sharded import ShardedOneSweep
     torch.cuda.set_device(0)
     keys = torch.empty(shard, dtype=torch.int32, device="cuda")
-    g.init_random(keys, 10 + 1000 * rank, andc)
+    slack = 3.0
+    if andc < 0:  # one top byte holds ~90 % of the keys: forces the 12-bit prefix split
+        g.init_random(keys, 10 + 1000 * rank, 0)
+        pick = torch.empty(shard, dtype=torch.int32, device="cuda")
+        g.init_random(pick, 99 + rank, 0)
+        heavy = (pick.to(torch.int64) & 0xFFFFFFFF) % 10 != 0
+        keys = torch.where(heavy, (keys & 0x00FFFFFF) | 0x5A000000, keys).contiguous()
+        slack = 1.25
+    else:
+        g.init_random(keys, 10 + 1000 * rank, andc)
     vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
     k0 = keys.cpu().numpy().view(np.uint32).copy()
     v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
-    s = ShardedOneSweep(shard, slack=3.0, pairs=pairs, value_bytes=4)   # HipLocalEngine
+    s = ShardedOneSweep(shard, slack=slack, pairs=pairs, value_bytes=4)   # HipLocalEngine
     bk, bv, nb = s.sort(keys, values=vals)
     torch.cuda.synchronize()
     s.engine.sorter.check()
+    assert s.last_split == ("12-bit prefix" if andc < 0 else "top byte"), s.last_split
     q.put((rank, k0, v0, bk.cpu().numpy().view(np.uint32).copy(), None if bv is None else bv.cpu().numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -44,7 +54,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (1 << 20) + 77), (3, 0, True, 300001), (2, 1, True, (1 << 18) + 5)])
+@pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (1 << 20) + 77), (3, 0, True, 300001), (2, 1, True, (1 << 18) + 5),
+                                                    (2, -1, False, (1 << 19) + 9), (3, -1, True, 200003)])
 def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

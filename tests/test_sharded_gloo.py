@@ -44,6 +44,20 @@ class OracleEngine:
             self._np(out, n)[:] = ko
             self._np(values_out, n)[:] = vo
 
+    def fine_histogram(self, keys, n):
+        k = self._np(keys, n)
+        return np.bincount((k >> np.uint32(20)).astype(np.int64), minlength=4096).astype(np.int64)
+
+    def partition_by_top12(self, keys, out, tmp, n, values=None, values_out=None, values_tmp=None):
+        k = np.ascontiguousarray(self._np(keys, n))
+        if values is None:
+            self._np(out, n)[:] = self.o.digit_pass(self.o.digit_pass(k, 16), 24)
+        else:
+            k1, v1 = self.o.digit_pass(k, 16, vals=np.ascontiguousarray(self._np(values, n)))
+            k2, v2 = self.o.digit_pass(k1, 24, vals=v1)
+            self._np(out, n)[:] = k2
+            self._np(values_out, n)[:] = v2
+
     def sort(self, keys, n, values=None):
         k = np.ascontiguousarray(self._np(keys, n))
         if values is None:
@@ -65,12 +79,22 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     import oracle_lib
     from gpusorting_amd.sharded import ShardedOneSweep
     o = oracle_lib.load()
-    keys = o.init_random(shard, 10 + 1000 * rank, andc)
+    slack = 4.0
+    if andc < 0:  # one top byte holds 90 % of the keys: the top-byte split cannot balance, the 12-bit one can
+        keys = o.init_random(shard, 10 + 1000 * rank, 0)
+        heavy = o.init_random(shard, 99 + rank, 0) % np.uint32(10) != 0
+        keys = np.where(heavy, (keys & np.uint32(0x00FFFFFF)) | np.uint32(0x5A000000), keys).astype(np.uint32)
+        slack = 1.25
+    else:
+        keys = o.init_random(shard, 10 + 1000 * rank, andc)
     vals = (np.arange(shard, dtype=np.uint32) + np.uint32(rank * shard)) if pairs else None
-    s = ShardedOneSweep(shard, engine=OracleEngine(), slack=4.0, pairs=pairs, value_bytes=4)
+    s = ShardedOneSweep(shard, engine=OracleEngine(), slack=slack, pairs=pairs, value_bytes=4)
     tk = torch.from_numpy(keys.view(np.int32).copy())
     tv = torch.from_numpy(vals.view(np.int32).copy()) if pairs else None
     bk, bv, nb = s.sort(tk, values=tv)
+    assert s.last_split == ("12-bit prefix" if andc < 0 else "top byte"), s.last_split
+    if andc < 0:
+        assert nb <= s.capacity and abs(nb - shard) < 0.2 * shard, (nb, shard)   # balanced after all
     q.put((rank, keys, vals, bk.numpy().view(np.uint32).copy(), None if bv is None else bv.numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,7 +106,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,andc,pairs", [(2, 0, False), (2, 0, True), (3, 0, False), (2, 2, True)])
+@pytest.mark.parametrize("world,andc,pairs", [(2, 0, False), (2, 0, True), (3, 0, False), (2, 2, True),
+                                              (2, -1, False), (3, -1, True)])   # -1: skewed top byte -> 12-bit split
 def test_sharded_sort_gloo(world, andc, pairs):
     shard = 20011
     ctx = mp.get_context("spawn")
