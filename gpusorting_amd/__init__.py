@@ -5,6 +5,7 @@ Only the hot path of b0nes164/GPUSorting named by BASELINE.json is here:
   csrc/      hand-written gfx950 HIP kernels + the C-ABI (include/gpusort.h)
   onesweep   host-side mirror of the reference interface (ctypes over the C-ABI)
   sharded    one-process-per-GPU MSD split + RCCL all-to-all-v + local OneSweep
+  functional sort / sort_ / argsort on torch tensors (plumbing over OneSweep)
 """
 from .onesweep import (  # noqa: F401
     ENTROPY_PRESET_1, ENTROPY_PRESET_2, ENTROPY_PRESET_3, ENTROPY_PRESET_4, ENTROPY_PRESET_5,
@@ -12,3 +13,4 @@ from .onesweep import (  # noqa: F401
     GPUSortingConfig, OneSweep, OneSweepDispatcher, init_random, validate,
 )
 from ._lib import GpuSortError  # noqa: F401
+from .functional import argsort, sort, sort_  # noqa: F401

@@ -691,3 +691,26 @@ def test_two_handles_on_two_streams_concurrently(gpu, oracle):
     np.testing.assert_array_equal(to_host(dv2, np.uint32), rv)
     h1.close()
     h2.close()
+
+
+def test_tensor_convenience_layer(gpu, oracle):
+    """gpusorting_amd.sort / sort_ / argsort: dtype -> key type, cached handles, growing sizes."""
+    import torch
+    for n in (1, 5, 40000, 70000, (1 << 20) + 1, 1000):          # the cached handle grows and is reused
+        bits = oracle.init_random(n, n + 9, 1)
+        for dtype, kt in ((torch.int32, 1), (torch.float32, 2)):
+            t = torch.from_numpy(bits.view(np.int32)).cuda().view(dtype)
+            for desc in (False, True):
+                out = gpu.sort(t, descending=desc)
+                np.testing.assert_array_equal(out.view(torch.int32).cpu().numpy().view(np.uint32),
+                                              oracle.std_sort(bits, kt, int(desc)), err_msg=f"n={n} {dtype} desc={desc}")
+        t = torch.from_numpy(bits.view(np.int32)).cuda()
+        vals = torch.arange(n, dtype=torch.int64, device="cuda")
+        k2, v2 = gpu.sort(t, vals, unsigned=True)
+        rk, rv = oracle.std_sort(bits, 0, 0, np.arange(n, dtype=np.uint64))
+        np.testing.assert_array_equal(k2.cpu().numpy().view(np.uint32), rk)
+        np.testing.assert_array_equal(v2.cpu().numpy().view(np.uint64), rv)
+        perm = gpu.argsort(t, unsigned=True)
+        np.testing.assert_array_equal(perm.cpu().numpy().astype(np.uint64), rv)   # stable: same permutation
+    with pytest.raises(TypeError):
+        gpu.sort(torch.zeros(8, dtype=torch.int64, device="cuda"))
