@@ -94,16 +94,21 @@ gs_status gs_onesweep_sort_pairs(gs_onesweep* h, void* d_keys, void* d_vals, voi
                                  gs_order order, void* stream);
 
 /* Synchronises `stream` and reads the device status word of the last sort:
- * GS_OK or GS_ERR_TIMEOUT.  (The reference checks nothing; D3D12 only warns,
- * GPUSortingD3D12/SweepBase.h:52-53.) */
+ * GS_OK or GS_ERR_TIMEOUT.  With the look-back fallback of the default build (a tile that
+ * waits too long recounts its predecessor itself) a timeout cannot occur; the word exists
+ * for builds without it (-DGS_FALLBACK=0), whose bounded spins report here instead of hanging.
+ * (The reference checks nothing; D3D12 only warns, GPUSortingD3D12/SweepBase.h:52-53.) */
 gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
 
 /* ---- tuning (no reference counterpart at run time; the reference fixes its
  * tile shape with #defines, GPUSortingCUDA/Sort/OneSweep.cu:30-36, and the D3D12
  * tree picks one per device in Tuner.h) -------------------------------------
- * Select one of the compiled tile shapes (threads x keys-per-thread).  The
- * default is what gs_onesweep_partition_size() reports.  Non-default shapes
- * are compiled for uint32 keys only.  Env GPUSORT_SHAPE="TxK" sets it at create. */
+ * Select one of the compiled tile shapes (threads x keys-per-thread).  Without a
+ * choice the library picks: the shape gs_onesweep_partition_size() reports for large
+ * sorts (512x32 keys-only and 8-byte values, 1024x16 4-byte values) and 512x16
+ * (8192-key tiles) up to 2^23 / 2^24 / 2^25 keys (keys-only / 4-byte / 8-byte values),
+ * where it is faster.  512x32, 1024x16 and 512x16 exist for every key and value type;
+ * 256x32 and 256x16 (tuning) for uint32 keys only.  Env GPUSORT_SHAPE="TxK" sets it at create. */
 gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread);
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
 /* Ranking algorithm inside a tile: 0 = 64-lane ballot multi-split (the
