@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 namespace {
@@ -256,8 +257,10 @@ extern "C" gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed,
 namespace {
 bool lds_atomic_order_ok() {
     static int cached[64];  // per device: 0 unknown, 1 ok, 2 failed
+    static std::mutex guard;  // handles may be created from several host threads
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(guard);
     if (cached[dev] == 0) {
         uint64_t fails = 1;
         const gs_status st = gs_selftest_lds_atomic_order(64, 0x9e3779b9u, &fails, nullptr);

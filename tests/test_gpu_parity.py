@@ -714,3 +714,40 @@ def test_tensor_convenience_layer(gpu, oracle):
         np.testing.assert_array_equal(perm.cpu().numpy().astype(np.uint64), rv)   # stable: same permutation
     with pytest.raises(TypeError):
         gpu.sort(torch.zeros(8, dtype=torch.int64, device="cuda"))
+
+
+def test_two_host_threads_each_with_its_own_handle(gpu, oracle):
+    """One handle per thread (include/gpusort.h): creation (incl. the once-per-device LDS probe) and sorting from
+    two host threads at the same time; ctypes releases the GIL around every call."""
+    import threading
+    import torch
+    errors = []
+
+    def work(seed, n, pairs):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            keys = oracle.init_random(n, seed, 1)
+            vals = np.arange(n, dtype=np.uint32) if pairs else None
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if pairs else gpu.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+                    dk = to_dev(keys)
+                    dv = None if vals is None else to_dev(vals)
+                    s.sort(dk, dv)
+                    s.check(stream)
+                    ref = oracle.std_sort(keys, 0, 0, vals)
+                    rk, rv = (ref, None) if vals is None else ref
+                    np.testing.assert_array_equal(to_host(dk, np.uint32), rk)
+                    if pairs:
+                        np.testing.assert_array_equal(to_host(dv, np.uint32), rv)
+                    s.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(31, 300007, False)), threading.Thread(target=work, args=(32, (1 << 20) + 5, True))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
