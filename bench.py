@@ -82,9 +82,12 @@ def pmc_traffic(args, sorter):
     separate rocprofv3 --pmc passes of this same command and committed under profiles/); None if the committed
     measurement is for another workload/tile shape."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.pairs or args.log2_keys != 28 or args.entropy or not os.path.exists(path):
+    if args.log2_keys != 28 or args.entropy or args.shape or not os.path.exists(path):
         return None
     d = json.load(open(path))
+    if args.pairs:
+        d = d.get(f"pairs{args.pairs}")
+        return d["traffic_bytes_per_launch"] if d else None
     return d["traffic_bytes_per_launch"] if f"<{sorter.partition_size // 32},32,0,0," in d["kernel"] else None
 
 
