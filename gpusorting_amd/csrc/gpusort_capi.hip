@@ -4,8 +4,10 @@
 // Replaces the dispatch half of the reference's OneSweepDispatcher
 // (GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:301-391): state clear, the
 // 1 + 1 + 4 launch sequence, validation read-back.  Differences by design:
-//   - one hipMemsetAsync over ONE contiguous slab instead of 6 cudaMemset
-//     (:301-309) and no host sync inside the sort (:318);
+//   - no clear launch at all (the reference: 6 cudaMemset, :301-309): the scan state is ONE contiguous slab that
+//     the GlobalHistogram kernel zeroes while it reads the keys; no host sync inside the sort (:318);
+//   - the pass plan (identity passes dropped, input buffer of each pass, skew / heavy-value handling) is made by
+//     the Scan kernel on the device;
 //   - descriptor rows = tiles + 1, so the last tile's publish to row tile+1
 //     stays in bounds (the reference overruns by 256 words when size==maxSize);
 //   - everything is enqueued on the caller's stream.
