@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--entropy", type=int, default=0, help="ENTROPY_PRESET index 0..4")
     ap.add_argument("--shape", type=str, default="", help="tile shape TxK (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-more", action="store_true", help="skip the 'more' block (configs[2], configs[4], entropy rows) of the N=1 run")
+    ap.add_argument("--more-steps", type=int, default=5, help="timed sorts per entry of the 'more' block")
     ap.add_argument("--dry-backend", type=str, default="", help="rehearsal of the N>1 code path on a one-GPU box: 'gloo' = "
                     "every rank on cuda:0, collectives over gloo (host-staged); never used for reported numbers")
     ap.add_argument("--cpu-log2", type=int, default=28, help="keys of the host-sort baseline sample (default: the workload itself)")
@@ -85,18 +87,124 @@ def cpu_baseline(log2n: int):
     }
 
 
-def pmc_traffic(args, sorter):
+def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys):
     """HBM bytes per DigitBinningPass launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
     separate rocprofv3 --pmc passes of this same command and committed under profiles/); None if the committed
     measurement is for another workload/tile shape."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.log2_keys != 28 or args.entropy or args.shape or not os.path.exists(path):
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    if log2_keys != 28 or entropy or shape:
         return None
     d = json.load(open(path))
-    if args.pairs:
-        d = d.get(f"pairs{args.pairs}")
+    if vb:
+        d = d.get(f"pairs{vb}")
         return d["traffic_bytes_per_launch"] if d else None
-    return d["traffic_bytes_per_launch"] if f"<{sorter.partition_size // 32},32,0,0," in d["kernel"] else None
+    m = d.get("tile_keys")
+    if m is not None:
+        return d["traffic_bytes_per_launch"] if m == tile_keys else None
+    return d["traffic_bytes_per_launch"] if f"<{tile_keys // 32},32,0,0," in d["kernel"] else None
+
+
+def roofline_block(n, vb, prof, traffic):
+    """The dominant kernel (one DigitBinningPass launch) against the HBM peak: algorithmic bytes per launch =
+    (4 + 4 key bytes + 2 x value bytes) x n, divided by the launch's average duration from HIP
+    events recorded on the sort's own stream."""
+    bpk_pass = 8 + 2 * vb
+    bpk_sort = 4 + 4 * bpk_pass
+    pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
+    achieved = bpk_pass * n / (pass_ms * 1e-3) / 1e9
+    whole = bpk_sort * n / (prof["total"] * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": "digit_binning_kernel (one 8-bit DigitBinningPass)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": bpk_pass * n, "avg_launch_ms": pass_ms,
+        "frac_of_measured_copy_6290": achieved / 6290.0,
+        "whole_sort": {
+            "bytes_per_key": bpk_sort, "ms": prof["total"], "achieved_GBs": whole, "frac_of_8000": whole / HBM_PEAK_GBS,
+            # BASELINE.json words the target as an "HBM-read roofline": the read half alone (SURVEY.md 8d)
+            "read_bytes_per_key": 4 + 4 * (4 + vb),
+            "read_only_frac_of_8000": (4 + 4 * (4 + vb)) * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        },
+        "per_kernel_ms": prof,
+    }
+
+
+def measure_single(g, n, vb, entropy, steps, warm=1, prof_reps=3):
+    """One 1-GPU configuration outside the headline region: `steps` back-to-back sorts of distinct pre-generated
+    inputs between device synchronisations (wall clock, same protocol as the headline), then `prof_reps` profiled
+    sorts for the per-kernel HIP-event times.  Returns (GKeys/s, ms per sort, profile, sorted?)."""
+    import torch
+    pairs = vb != 0
+    vdt = torch.int32 if vb == 4 else torch.int64
+    sorter = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=vb)
+    nb = max(steps, warm)
+    ks = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(nb)]
+    vs = [torch.empty(n, dtype=vdt, device="cuda") for _ in range(nb)] if pairs else [None] * nb
+    alt = torch.empty(n, dtype=torch.int32, device="cuda")
+    valt = torch.empty(n, dtype=vdt, device="cuda") if pairs else None
+
+    def gen(seed0):
+        for i in range(nb):
+            g.init_random(ks[i], seed0 + i, entropy, vs[i])
+        torch.cuda.synchronize()
+
+    gen(5000)
+    for i in range(warm):
+        sorter.sort(ks[i], vs[i], alt_keys=alt, alt_values=valt)
+    gen(10)  # reference seeds 10 + i (GPUSortingCUDA.cu:22)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        sorter.sort(ks[i], vs[i], alt_keys=alt, alt_values=valt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sorter.check()
+    ok = g.validate(ks[steps - 1], vs[steps - 1] if vb == 4 else None) == 0
+    sorter.set_profiling(True)
+    acc = {}
+    for r in range(prof_reps):
+        g.init_random(ks[0], 777 + r, entropy, vs[0])
+        torch.cuda.synchronize()
+        sorter.sort(ks[0], vs[0], alt_keys=alt, alt_values=valt)
+        for k_, v_ in sorter.get_profile().items():
+            acc[k_] = acc.get(k_, 0.0) + v_ / prof_reps
+    sorter.set_profiling(False)
+    tile = sorter.partition_size
+    sorter.close()
+    return n * steps / dt / 1e9, dt / steps * 1e3, acc, ok, tile
+
+
+def more_block(g, n, log2, steps):
+    """Driver-visible numbers for the other single-GPU configurations of BASELINE.json — configs[2] (u32 values),
+    configs[4] (u64 values, Thearling-Smith entropy sweep) — and the keys-only entropy row, each with the
+    roofline of its own dominant kernel.  Reference protocol: GPUSortingCUDA/GPUSortingCUDA.cu:36-39,
+    GPUSortingD3D12/Tests.h:383-387,406-410.  Runs after the headline's timed region; never part of `value`."""
+    ent_bits = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201
+    out = {"note": "measured after the headline region, same process; steps per entry = %d" % steps}
+    for vb, name, cfg in ((4, "pairs_u32", 2), (8, "pairs_u64", 4)):
+        gk, ms, prof, ok, tile = measure_single(g, n, vb, 0, steps)
+        out[name] = {
+            "workload": f"2^{log2} (uint32 key, uint{8 * vb} value) pairs OneSweep, 1 MI355X (BASELINE configs[{cfg}])",
+            "value": gk, "unit": "GKeys/s", "ms_per_sort": ms, "steps": steps, "tile_keys": tile, "verified_sorted": bool(ok),
+            "dtype": f"u32 keys + u{8 * vb} values",
+            "roofline": roofline_block(n, vb, prof, pmc_traffic(log2, vb, 0, "", tile)),
+        }
+    rows = {}
+    for vb, name in ((0, "keys"), (8, "pairs_u64")):
+        row = []
+        for preset in range(5):
+            gk, ms, prof, ok, tile = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
+            pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
+            row.append({"preset": preset + 1, "entropy_bits": ent_bits[preset], "value": gk, "unit": "GKeys/s", "ms_per_sort": ms,
+                        "verified_sorted": bool(ok), "global_histogram_ms": prof["global_histogram"], "avg_pass_ms": pass_ms,
+                        "pass_frac_of_8000": (8 + 2 * vb) * n / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        rows[name] = row
+    out["entropy_sweep"] = rows
+    return out
 
 
 def main():
@@ -230,10 +338,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    bytes_per_key_pass = 8 + 2 * args.pairs            # read + write of key (+ value) per DigitBinningPass
-    bytes_per_key_sort = 4 + 4 * bytes_per_key_pass    # + one histogram read (36 / 68 / 100)
-    pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
-    achieved = bytes_per_key_pass * n / (pass_ms * 1e-3) / 1e9
     total_keys = n * world * K
     value = total_keys / elapsed / 1e9
     ms_per_step = elapsed / K * 1e3
@@ -251,23 +355,16 @@ def main():
             "keys_per_gpu": n, "entropy_preset": args.entropy + 1, "generator": "InitRandom seed 10+i (+1000*rank)",
             "tile_keys": sorter.partition_size, "verified_sorted": bool(sorted_ok and total_ok),
         },
-        "roofline": {
-            "bound": "hbm", "kernel": "digit_binning_kernel (one 8-bit DigitBinningPass)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args, sorter),
-            "algorithmic_bytes_per_launch": bytes_per_key_pass * n, "avg_launch_ms": pass_ms,
-            "frac_of_measured_copy_6290": achieved / 6290.0,
-            "whole_sort": {
-                "bytes_per_key": bytes_per_key_sort, "ms": prof["total"],
-                "achieved_GBs": bytes_per_key_sort * n / (prof["total"] * 1e-3) / 1e9,
-                "frac_of_8000": bytes_per_key_sort * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                # BASELINE.json words the target as an "HBM-read roofline": the read half alone
-                "read_bytes_per_key": 4 + 4 * (4 + args.pairs),
-                "read_only_frac_of_8000": (4 + 4 * (4 + args.pairs)) * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            },
-            "per_kernel_ms": prof,
-        },
+        "roofline": roofline_block(n, args.pairs, prof, pmc_traffic(args.log2_keys, args.pairs, args.entropy, args.shape, sorter.partition_size)),
     }
+    if world == 1 and not args.pairs and not args.entropy and not args.shape and not args.no_more:
+        # free the headline's buffers first: the block allocates its own
+        bufs.clear()
+        vbufs.clear()
+        last = out_k = out_v = None
+        sorter.close()
+        torch.cuda.empty_cache()
+        out["more"] = more_block(g, n, args.log2_keys, args.more_steps)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_log2)
     else:

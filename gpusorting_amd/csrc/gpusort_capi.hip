@@ -75,6 +75,7 @@ const Shape g_shapes[] = {
     GS_FULL(512, 16),   // mid sizes (n <= mid_keys): 8192-key tiles, shorter per-tile latency, more workgroups
 #ifndef GS_NO_TUNING_SHAPES
     GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
+    GS_U32ONLY(512, 20),  // 10 240-key tiles: 52 KiB of LDS, three workgroups per CU
 #endif
 };
 constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
@@ -118,6 +119,9 @@ struct gs_onesweep {
     uint32_t msd_n, msd_grid;
     gs_key_type msd_kt;
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
+    // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
+    uint32_t last_n, last_tile, last_p0, last_np, last_dyn, last_desc_stride;
+    bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
 };
 
 namespace {
@@ -163,8 +167,13 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // position segments of the first pass: equal, multiples of the histogram chunk
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
     // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
+    // The histogram kernel ACCUMULATES into HIST and relies on it being zero between calls (the first pass
+    // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
+    // between left it dirty: zero it here, once, instead of double counting silently.
+    if (h->hist_dirty) GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
+    h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
@@ -175,6 +184,8 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->desc_stride = desc_stride;
+    h->last_n = n; h->last_tile = tile; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u;
+    h->last_desc_stride = desc_stride;
     return GS_OK;
 }
 
@@ -213,6 +224,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     if (SmallLauncher small = h->small_path ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
+        h->last_tile = 0;
         if (h->profiling)  // everything is charged to slot 0 (and the total)
             for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
         GS_HIP(hipGetLastError());
@@ -248,6 +260,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
     }
     GS_HIP(hipGetLastError());
+    h->hist_dirty = false;  // pass 0 (mode bit 2) was launched: it zeroes HIST
     h->profile_pending = h->profiling != 0;
     return GS_OK;
 }
@@ -337,6 +350,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->pinned = nullptr;
     h->trace_buf = nullptr;
     h->msd_keys = nullptr;
+    h->last_n = h->last_tile = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
+    h->hist_dirty = false;
     h->msd_n = h->msd_grid = 0;
     h->msd_kt = GS_KEY_UINT32;
     h->slab_words = slab_words_for(max_keys);
@@ -480,6 +495,26 @@ gs_status gs_onesweep_check(gs_onesweep* h, void* stream) {
     return h->pinned[0] == gs::STATUS_OK ? GS_OK : GS_ERR_TIMEOUT;
 }
 
+gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream) {
+    if (!h || !report) return GS_ERR_ARG;
+    for (int i = 0; i < 8; ++i) report[i] = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->last_tile == 0) return GS_OK;  // single-tile sort or nothing yet: there is no scan state to check
+    unsigned long long* d = nullptr;
+    GS_HIP(hipMalloc(&d, 8 * sizeof(unsigned long long)));
+    gs_status ret = GS_OK;
+    if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) ret = GS_ERR_HIP;
+    if (ret == GS_OK) {
+        hipLaunchKernelGGL(gs::check_state_kernel, dim3(gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
+                           h->last_tile, 0u, h->last_dyn, d);
+        if (hipMemcpyAsync(report, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            ret = GS_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return ret;
+}
+
 gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, uint32_t* h_hist,
                                        void* stream) {
     if (!h || !d_keys || !h_hist || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
@@ -491,6 +526,7 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
     const size_t words = 4 * (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
+    h->hist_dirty = false;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t q = 0; q < 4; ++q)  // digit totals = joint histogram summed over chains
         for (uint32_t d = 0; d < gs::RADIX; ++d) {
@@ -525,6 +561,7 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, pass * 8,
        (reverse_index ? 1u : 0u) | 4u);
     GS_HIP(hipGetLastError());
+    h->hist_dirty = false;
     if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
         for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
     h->profile_pending = h->profiling != 0;
@@ -543,6 +580,7 @@ gs_status gs_onesweep_msd_prepare(gs_onesweep* h, const void* d_keys, uint32_t n
     const size_t words = (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // msd_partition may never be called
+    h->hist_dirty = false;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t d = 0; d < gs::RADIX; ++d) {
         uint32_t g = 0;
@@ -682,6 +720,7 @@ gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uin
     const size_t words = 2 * (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
+    h->hist_dirty = false;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t d = 0; d < gs::RADIX; ++d)
         for (uint32_t x = 0; x < gs::NCH; ++x) h_hist4096[d * gs::NCH + x] = h->pinned[gs::hist_index(1, d, x)];

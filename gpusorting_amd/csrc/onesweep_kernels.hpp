@@ -107,6 +107,9 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 #ifndef GS_FUSED_PAIRS
 #define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
 #endif
+#ifndef GS_ONEWAVE_REDUCE
+#define GS_ONEWAVE_REDUCE 1  // the per-tile digit fold (prefix over waves, totals, 256-digit scan) by one wave on 16-byte LDS accesses
+#endif
 #ifndef GS_HEAVY_SHARE
 #define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
                            // gain nothing over the digit-group chains and the counting still costs
@@ -229,6 +232,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
         uint32_t t = __shfl_up(v, d, 64);
         if (lane >= (uint32_t)d) v += t;
     }
+    return v;
+}
+
+// the same scan on the VALU's data-parallel primitives: four row shifts inside each 16-lane row, then the two
+// row broadcasts (lane 15 -> next row of each row pair, lane 31 -> the upper half).  No LDS round trips (the
+// shuffle form costs six dependent ds_bpermute, ~0.3 us in the per-tile critical path).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
     return v;
 }
 
@@ -654,8 +670,12 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     if (tid == 64) s_misc[3] = ld_agent(status);
     if (tid >= 128 && tid < 134) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, cnt_h, cnt_start, cnt_sublen, xh
     __syncthreads();
-    if (s_misc[3] != STATUS_OK) return;
-    const uint32_t pflags = s_misc[9];
+    // Everything below that is the same for the whole workgroup is made SCALAR explicitly (values read from LDS
+    // or through a VGPR index are vector registers to the compiler: pointers selected by them cost two VGPRs
+    // each and a 64-bit vector add per access, and every branch on them is an exec-mask branch).
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    if (uni(s_misc[3]) != STATUS_OK) return;
+    const uint32_t pflags = uni(s_misc[9]);
     if ((mode & 2u) && (pflags & PF_SKIP)) return;  // identity pass of a full sort
 #ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with GPUSORT_SKIP_PASSES=0)
     const bool swapped = false;
@@ -667,13 +687,13 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const void* vals_in_ = swapped ? vals_b : vals_a;
     void* vals_out_ = swapped ? vals_a : vals_b;
     const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
-    const uint32_t nch = s_misc[10];                                      // chains of this pass (NCH or MAXCH)
-    const uint32_t cnt_h = (Cfg::HEAVY && (mode & 2u)) ? s_misc[11] : 0xffffffffu;  // heavy value this pass counts for the next one
-    const uint32_t cnt_start = s_misc[12], cnt_sublen = s_misc[13];
-    uint32_t tile = s_misc[1];
+    const uint32_t nch = uni(s_misc[10]);                                 // chains of this pass (NCH or MAXCH)
+    const uint32_t cnt_h = (Cfg::HEAVY && (mode & 2u)) ? uni(s_misc[11]) : 0xffffffffu;  // heavy value this pass counts for the next one
+    const uint32_t cnt_start = uni(s_misc[12]), cnt_sublen = uni(s_misc[13]);
+    uint32_t tile = uni(s_misc[1]);
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
-    uint32_t seg_start = info[I_START + chain], seg_end = info[I_END + chain];
+    uint32_t seg_start = uni(info[I_START + chain]), seg_end = uni(info[I_END + chain]);
     if (GS_UNLIKELY(tile >= chain_tiles(seg_start, seg_end, TILE))) {  // uniform
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
@@ -718,11 +738,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if (lane == 0) { s_misc[0] = got_x; s_misc[1] = got_t; }
         }
         __syncthreads();
-        chain = s_misc[0];
-        tile = s_misc[1];
+        chain = uni(s_misc[0]);
+        tile = uni(s_misc[1]);
         if (tile == 0xffffffffu) return;  // every chain is fully claimed
-        seg_start = info[I_START + chain];
-        seg_end = info[I_END + chain];
+        seg_start = uni(info[I_START + chain]);
+        seg_end = uni(info[I_END + chain]);
     }
     const uint32_t tile_base = (seg_start & ~63u) + tile * TILE;
     const uint32_t lo = tile_base > seg_start ? tile_base : seg_start;  // valid keys: [lo, hi)
@@ -730,14 +750,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t count = hi - lo;
     const uint32_t head = lo - tile_base;  // masked keys in front (first tile of a chain only)
     const bool full = (count == TILE);
-    uint32_t* cdesc = desc + (size_t)info[I_ROW + chain] * RADIX;  // row 0 of this chain
+    uint32_t* cdesc = desc + (size_t)uni(info[I_ROW + chain]) * RADIX;  // row 0 of this chain
     // Heavy layout: the slices of the heavy value's run (chains < NCH) and the digits above it (chain 2*NCH)
     // start where the counts gathered by the PREVIOUS pass say — tile 0 of such a chain seeds its row 0 now,
     // long before a successor can walk that far: seed of the heavy group's chain (set by scan_kernel)
     // + keys of that group below the heavy value + the slices in front of this one.
     if (GS_UNLIKELY(Cfg::HEAVY && (pflags & PF_HEAVY) && tile == 0u && (chain < NCH || chain == 2 * NCH) && tid < RADIX)) {
         const uint32_t* hs = hsub + (shift >> 3) * HSUB_STRIDE;
-        const uint32_t grp_chain = NCH + s_misc[14];
+        const uint32_t grp_chain = NCH + uni(s_misc[14]);
         uint32_t seed = ld_agent(&desc[(size_t)info[I_ROW + grp_chain] * RADIX + tid]) >> 2;
         seed += hs[NCH * RADIX + tid];
         const uint32_t in_front = chain < NCH ? chain : NCH;
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             // LDS queue).  The guess is relearned from the first lane whenever it covers < 8 lanes; that decision
             // needs ballots only, never a returned value, so the atomics of SKEW_CHUNK rounds are issued back to
             // back and resolved together (one dependent LDS round trip per chunk instead of two per key).
-            constexpr int SKEW_CHUNK = 8;
+            constexpr int SKEW_CHUNK = KPT % 8 == 0 ? 8 : 4;
             static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
             uint32_t sticky = 0xffffffffu;  // wave-uniform
 #pragma unroll
@@ -917,7 +937,58 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     __syncthreads();
 
     // ---- per-digit: exclusive prefix over waves, tile total, publish, digit scan ----
-    uint32_t tile_total = 0, scan_incl = 0, dpre = 0;
+    uint32_t tile_total = 0, scan_incl = 0, dpre = 0, dummies = 0;
+    // the tile's trailing dummies are not ranked (and later not staged) in the plain LDS-atomic ranking path
+    const bool tail_unranked = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
+#if GS_ONEWAVE_REDUCE
+    // ONE wave does the whole fold, four digits per lane on 16-byte LDS accesses: exclusive prefix over the
+    // waves, tile totals (published as REDUCTION with two 8-byte sc1 stores per lane: the row is 1 KiB
+    // contiguous), the 256-digit scan on the VALU (DPP), the stage offsets folded back into the per-wave
+    // bases.  One barrier instead of two, 18 wide LDS operations instead of 128 dword ones, and no LDS
+    // round trips inside the scan.  The look-back threads pick their digit's total and offset up from LDS.
+    if (wave == 0) {
+        uint4 run4 = {0u, 0u, 0u, 0u};  // digit totals of the tile (dummies included)
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint4 t = reinterpret_cast<const uint4*>(s_whist + w * RADIX)[lane];
+            run4.x += t.x; run4.y += t.y; run4.z += t.z; run4.w += t.w;
+            if (w == WAVES / 2 - 1) asm volatile("" ::: "memory");  // two batches of reads in flight, not all rows: registers
+        }
+        uint4 tt = run4;  // real keys only (see the dword form below)
+        if (lane == 0) tt.x -= head;
+        if (lane == 63 && !full && !tail_unranked) tt.w -= TILE - head - count;
+        if (!GS_FAULT_TILE(chain, tile)) {
+            unsigned long long* row = reinterpret_cast<unsigned long long*>(&cdesc[(size_t)(tile + 1u) * RADIX + 4u * lane]);
+            __hip_atomic_store(row, (unsigned long long)((tt.x << 2) | FLAG_REDUCTION) | ((unsigned long long)((tt.y << 2) | FLAG_REDUCTION) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 1, (unsigned long long)((tt.z << 2) | FLAG_REDUCTION) | ((unsigned long long)((tt.w << 2) | FLAG_REDUCTION) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t lane_sum = run4.x + run4.y + run4.z + run4.w;
+        const uint32_t excl = wave_inclusive_scan_dpp(lane_sum) - lane_sum;
+        const uint4 dp = {excl, excl + run4.x, excl + run4.x + run4.y, excl + run4.x + run4.y + run4.z};
+        reinterpret_cast<uint4*>(s_dpre)[lane] = dp;
+        reinterpret_cast<uint4*>(s_gbase)[lane] = tt;  // parked here until the look-back overwrites it with the base
+        // second sweep over the per-wave counts (re-read: keeping all eight rows in registers next to the tile's
+        // keys spilled): count -> stage offset of (wave, digit) = digit offset + counts of the waves in front
+        uint4 acc = dp;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            uint4* row = reinterpret_cast<uint4*>(s_whist + w * RADIX) + lane;
+            const uint4 t = *row;
+            *row = acc;
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            if (w == WAVES / 2 - 1) asm volatile("" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        tile_total = s_gbase[tid];
+        dpre = s_dpre[tid];
+        dummies = (tid == 0 ? head : 0u) + ((tid == RADIX - 1 && !full && !tail_unranked) ? TILE - head - count : 0u);
+    }
+    (void)scan_incl;
+#else
     if (tid < RADIX) {
         uint32_t run = 0;
 #pragma unroll
@@ -926,7 +997,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             s_whist[w * RADIX + tid] = run;
             run += c;
         }
-        tile_total = run - (tid == 0 ? head : 0u);  // published counts exclude the front dummies
+        // published counts are the tile's REAL keys: without the dummies in front (digit 0) and, where they were
+        // ranked at all (ballot ranking, skewed passes), without the dummies behind the segment (digit 255) — the
+        // same numbers a fallback recount of this tile produces
+        dummies = (tid == 0 ? head : 0u) + ((tid == RADIX - 1 && !full && !tail_unranked) ? TILE - head - count : 0u);
+        tile_total = run - dummies;
         if (!GS_FAULT_TILE(chain, tile))
             st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], (tile_total << 2) | FLAG_REDUCTION);
         scan_incl = wave_inclusive_scan(run, lane);
@@ -936,17 +1011,18 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     if (tid < RADIX) {
         uint32_t wbase = 0;
         for (uint32_t w = 0; w < wave; ++w) wbase += s_misc[4 + w];
-        dpre = wbase + scan_incl - (tile_total + (tid == 0 ? head : 0u));  // stage offset of the run (dummies included)
+        dpre = wbase + scan_incl - (tile_total + dummies);  // stage offset of the run (dummies included)
         s_dpre[tid] = dpre;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
     }
     __syncthreads();
+#endif
 
     GS_TRACE(3);
     // ---- stage keys in LDS, sorted by digit (stable) ----
     // mask_tail: the tile's trailing dummies were not ranked (above) and are not staged
-    const bool mask_tail = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
+    const bool mask_tail = tail_unranked;
     // fused pairs: slot = (key, value); 4-byte values as one 8-byte LDS word, 8-byte values in a second array
     auto stage_pair = [&](uint32_t slot, uint32_t k, V v) {
         if constexpr (VB == 4) {
@@ -1069,7 +1145,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
         __syncthreads();
         if (!GS_FALLBACK) break;
-        const uint32_t fb_row = s_misc[8];  // uniform
+        const uint32_t fb_row = uni(s_misc[8]);  // uniform
         if (GS_LIKELY(fb_row == 0u)) break;
         // ---- fallback: some digit's walk waited FALLBACK_SPINS polls on row fb_row.  The whole workgroup
         // recounts that tile's digits from the pass input (which nobody writes during the pass), offers the
@@ -1082,8 +1158,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             const uint32_t flo = fbase > seg_start ? fbase : seg_start;
             const uint32_t fhi = (seg_end - fbase < TILE) ? seg_end : fbase + TILE;
             for (uint32_t i = tid; i < RADIX; i += THREADS) s_fb[i] = 0;
-            if (tid == 0) s_misc[8] = 0u;
             __syncthreads();
+            // every thread has read the request (fb_row above) before it is withdrawn; the next request can only
+            // be posted after the barrier that ends this block
+            if (tid == 0) s_misc[8] = 0u;
             for (uint32_t idx = flo + tid; idx < fhi; idx += THREADS)
                 atomicAdd(&s_fb[(to_bits<KT>(keys_in[idx]) >> shift) & 255u], 1u);
             __syncthreads();
@@ -1103,7 +1181,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #if (GS_EXP & 2)
     if (tid == 0) trace[7] = trace_trips | (chain << 16) | (1u << 31);
 #endif
-    if (s_misc[2] != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
+    if (uni(s_misc[2]) != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----
@@ -1273,6 +1351,46 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Debug: post-sort invariants of the scan state (reference: ValidateInitialOneSweepState and the index/flag
+// checks around it, GPUSortingCUDA/UtilityKernels.cuh:482-502).  One workgroup per (pass, chain), one digit per
+// thread: walks the chain's descriptor rows 0..tiles and counts rows that are not INCLUSIVE, rows whose inclusive
+// count went down, chains whose ticket counter stayed below their tile count; adds (last row - row 0) into the
+// pass's key total.  Block (0,0) also counts non-zero words of the HIST region (which must be zero whenever no
+// call is in flight).  report: [0] rows not INCLUSIVE, [1] non-monotone rows, [2] chains with too few tickets,
+// [3] non-zero HIST words, [4 + pass] keys accounted for by the pass's descriptors.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, uint32_t desc_stride, uint32_t tile_keys,
+                                                           uint32_t p0, uint32_t dyn, unsigned long long* report) {
+    const uint32_t tid = threadIdx.x, q = blockIdx.y, chain = blockIdx.x;
+    if (q == 0 && chain == 0) {
+        uint32_t nz = 0;
+        for (uint32_t i = tid; i < 4 * NCH * RADIX; i += 256) nz += slab[SLAB_HIST + i] != 0u;
+        if (nz) atomicAdd(&report[3], (unsigned long long)nz);
+    }
+    const uint32_t* info = slab + SLAB_INFO + q * INFO_STRIDE;
+    if (dyn && (info[PASS_FLAGS] & PF_SKIP)) return;  // an identity pass that was dropped: nothing ran
+    if (chain >= info[I_NCH]) return;
+    const uint32_t tiles = chain_tiles(info[I_START + chain], info[I_END + chain], tile_keys);
+    if (tiles == 0) return;
+    const uint32_t* rows = slab + SLAB_DESC + (size_t)q * desc_stride + (size_t)info[I_ROW + chain] * RADIX;
+    if (tid == 0 && slab[SLAB_COUNTERS + ((p0 + q) * COUNTERS_PER_PASS + chain) * COUNTER_STRIDE] < tiles)
+        atomicAdd(&report[2], 1ull);
+    uint32_t bad_flag = 0, bad_mono = 0;
+    const uint32_t first = rows[tid];
+    uint32_t prev = first >> 2;
+    bad_flag += (first & FLAG_MASK) != FLAG_INCLUSIVE;
+    for (uint32_t r = 1; r <= tiles; ++r) {
+        const uint32_t v = rows[(size_t)r * RADIX + tid];
+        bad_flag += (v & FLAG_MASK) != FLAG_INCLUSIVE;
+        bad_mono += (v >> 2) < prev;
+        prev = v >> 2;
+    }
+    if (bad_flag) atomicAdd(&report[0], (unsigned long long)bad_flag);
+    if (bad_mono) atomicAdd(&report[1], (unsigned long long)bad_mono);
+    atomicAdd(&report[4 + q], (unsigned long long)(prev - (first >> 2)));
 }
 
 // ---------------------------------------------------------------------------

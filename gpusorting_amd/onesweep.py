@@ -53,6 +53,14 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
         raise ValueError(f"{name} must be a contiguous tensor on the GPU")
 
 
+def _require_room(t: torch.Tensor | None, n: int, name: str) -> None:
+    """The C-ABI takes raw pointers: every buffer handed over must hold at least n elements."""
+    if t is not None:
+        _require_cuda(t, name)
+        if n > t.numel():
+            raise ValueError(f"{name} holds {t.numel()} elements, n = {n}")
+
+
 def init_random(keys: torch.Tensor, seed: int, entropy_preset: int = ENTROPY_PRESET_1,
                 values: torch.Tensor | None = None, n: int | None = None) -> None:
     """InitRandom<<<256,256>>> (GPUSortingCUDA/UtilityKernels.cuh:53-117): fills keys (and values = key)."""
@@ -155,10 +163,18 @@ class OneSweep:
             raise ValueError("keys must be a 32-bit type")
         if (values is not None) != (self.mode == MODE_PAIRS):
             raise ValueError("values must be given exactly when the sorter was built with MODE_PAIRS")
-        if alt_keys is None:
-            alt_keys, own_alt_vals = self._alts(n, values)
+        _require_room(keys, n, "keys")
+        _require_room(values, n, "values")
+        if alt_keys is None or (values is not None and alt_values is None):
+            own_alt_keys, own_alt_vals = self._alts(n, values)
+            if alt_keys is None:
+                alt_keys = own_alt_keys
             if alt_values is None:
                 alt_values = own_alt_vals
+        _require_room(alt_keys, n, "alt_keys")
+        _require_room(alt_values if values is not None else None, n, "alt_values")
+        if alt_keys.element_size() != 4 or (values is not None and alt_values.element_size() != values.element_size()):
+            raise ValueError("alt buffers must have the element size of the buffers they shadow")
         s = _stream_ptr(stream)
         if values is None:
             st = self._lib.gs_onesweep_sort_keys(self._h, keys.data_ptr(), alt_keys.data_ptr(), n, self.key_type,
@@ -175,9 +191,17 @@ class OneSweep:
         """Synchronise and raise if the device reported a look-back timeout."""
         check(self._lib.gs_onesweep_check(self._h, _stream_ptr(stream)), "gs_onesweep_check")
 
+    def check_state(self, stream=None) -> dict:
+        """Post-call invariants of the chained-scan state (gs_debug_check_state): synchronises and returns the report."""
+        rep = (C.c_uint64 * 8)()
+        check(self._lib.gs_debug_check_state(self._h, rep, _stream_ptr(stream)), "gs_debug_check_state")
+        return {"rows_not_inclusive": int(rep[0]), "rows_not_monotone": int(rep[1]), "chains_short_of_tickets": int(rep[2]),
+                "hist_words_nonzero": int(rep[3]), "keys_per_pass": [int(rep[4 + q]) for q in range(4)]}
+
     # -- structural entry points ------------------------------------------------
     def global_histogram(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
         n = keys.numel() if n is None else int(n)
+        _require_room(keys, n, "keys")
         out = (C.c_uint32 * 1024)()
         check(self._lib.gs_onesweep_global_histogram(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
               "gs_onesweep_global_histogram")
@@ -187,6 +211,8 @@ class OneSweep:
                    values_in: torch.Tensor | None = None, values_out: torch.Tensor | None = None,
                    reverse_index: bool = False) -> None:
         n = keys_in.numel() if n is None else int(n)
+        for t, name in ((keys_in, "keys_in"), (keys_out, "keys_out"), (values_in, "values_in"), (values_out, "values_out")):
+            _require_room(t, n, name)
         check(self._lib.gs_onesweep_digit_pass(
             self._h, keys_in.data_ptr(), keys_out.data_ptr(),
             None if values_in is None else values_in.data_ptr(),
@@ -196,6 +222,7 @@ class OneSweep:
     def msd_prepare(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
         """Top-byte histogram of ``keys[:n]`` (256 counts); leaves histogram + scan in the handle for msd_partition."""
         n = keys.numel() if n is None else int(n)
+        _require_room(keys, n, "keys")
         out = (C.c_uint32 * 256)()
         check(self._lib.gs_onesweep_msd_prepare(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
               "gs_onesweep_msd_prepare")
@@ -203,8 +230,8 @@ class OneSweep:
 
     def msd_fine_histogram(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
         """4096-bin histogram of the 12-bit key prefix (top byte, top nibble of the next byte); synchronous."""
-        _require_cuda(keys, "keys")
         n = keys.numel() if n is None else int(n)
+        _require_room(keys, n, "keys")
         out = (C.c_uint32 * 4096)()
         check(self._lib.gs_onesweep_msd_fine_histogram(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
               "gs_onesweep_msd_fine_histogram")
@@ -213,6 +240,8 @@ class OneSweep:
     def msd_partition(self, keys_in: torch.Tensor, keys_out: torch.Tensor, n: int | None = None,
                       values_in: torch.Tensor | None = None, values_out: torch.Tensor | None = None) -> None:
         n = keys_in.numel() if n is None else int(n)
+        for t, name in ((keys_in, "keys_in"), (keys_out, "keys_out"), (values_in, "values_in"), (values_out, "values_out")):
+            _require_room(t, n, name)
         check(self._lib.gs_onesweep_msd_partition(
             self._h, keys_in.data_ptr(), keys_out.data_ptr(),
             None if values_in is None else values_in.data_ptr(),

@@ -143,6 +143,10 @@ class ShardedOneSweep:
         object's receive buffers holding this rank's range of the global result.
         """
         n = keys.numel() if n is None else int(n)
+        if n > keys.numel() or n > self.shard_keys or (values is not None and n > values.numel()):
+            raise ValueError(f"n = {n} exceeds the shard buffers (keys {keys.numel()}, shard capacity {self.shard_keys})")
+        if (values is not None) != self.pairs:
+            raise ValueError("values must be given exactly when the object was built with pairs=True")
         eng, W = self.engine, self.world
         if W == 1 and not self.always_exchange:
             self._recv[:n].copy_(keys[:n])

@@ -137,6 +137,15 @@ gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_
  * receives per-tile phase timestamps.  A no-op in the product build. */
 gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf);
 
+/* Debug: post-call invariants of the handle's chained-scan state (the analogue of the reference's
+ * ValidateInitialOneSweepState + index checks, GPUSortingCUDA/UtilityKernels.cuh:482-502, which the reference never
+ * calls after a sort).  Synchronous.  After any tiled call that completed: report[0] descriptor rows that are not
+ * INCLUSIVE, [1] rows whose inclusive count decreased along their chain, [2] chains whose ticket counter is below
+ * their tile count, [3] non-zero words left in the histogram region (it must be zero whenever no call is in
+ * flight) — all four must be 0 — and [4 + q] the keys the descriptors of the call's q-th pass account for (== n
+ * for every pass that ran, 0 for a dropped identity pass).  All zero after a single-tile sort (no scan state). */
+gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream);
+
 /* ---- structural entry points (parity tests, MSD split) --------------------
  * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
  * the four 256-bin histograms (counts, not prefixes) to h_hist[1024] on the

@@ -211,6 +211,42 @@ void gso_std_sort_parallel(uint32_t* keys, uint32_t n, uint32_t threads) {
     }
 }
 
+void gso_sort_permutation_parallel(const uint32_t* keys, uint32_t n, int key_type, int order, uint32_t threads,
+                                   uint32_t* perm) {
+    /* The defined result of a pairs sort (OneSweep.cu:346-600: every pass is a STABLE partition) is the stable
+     * order by key; with payload = original index that is the order of the 64-bit composites
+     * (sortable bits << 32 | index), which are all distinct — so an ordinary (unstable) comparison sort of the
+     * composites IS the stable sort, and it parallelises: chunked std::sort + merge tree.  Descending = exact
+     * reverse of the stable ascending result (SortCommon.hlsl:594-597,645-656). */
+    std::vector<uint64_t> c(n);
+    uint32_t chunks = 1;
+    while (chunks * 2 <= threads && (size_t)chunks * 2 * 65536 <= n) chunks *= 2;
+    std::vector<size_t> bound(chunks + 1);
+    for (uint32_t i = 0; i <= chunks; ++i) bound[i] = (size_t)n * i / chunks;
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < chunks; ++t)
+            pool.emplace_back([&, t] {
+                for (size_t i = bound[t]; i < bound[t + 1]; ++i)
+                    c[i] = ((uint64_t)gso_key_to_bits(keys[i], key_type) << 32) | (uint32_t)i;
+                std::sort(c.begin() + bound[t], c.begin() + bound[t + 1]);
+            });
+        for (auto& t : pool) t.join();
+    }
+    for (uint32_t width = 1; width < chunks; width *= 2) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t + width < chunks; t += 2 * width) {
+            const size_t lo = bound[t], mid = bound[t + width], hi = bound[std::min(t + 2 * width, chunks)];
+            pool.emplace_back([&c, lo, mid, hi] { std::inplace_merge(c.begin() + lo, c.begin() + mid, c.begin() + hi); });
+        }
+        for (auto& t : pool) t.join();
+    }
+    if (order == GSO_DESCENDING)
+        for (size_t i = 0; i < n; ++i) perm[n - 1 - i] = (uint32_t)c[i];
+    else
+        for (size_t i = 0; i < n; ++i) perm[i] = (uint32_t)c[i];
+}
+
 uint32_t gso_validate(const uint32_t* keys, const void* vals, uint32_t value_bytes, uint32_t n,
                       int key_type, int order) {
     /* UtilityKernels.cuh:403-429: count i with a[i] > a[i+1]; order/type-aware as

@@ -96,6 +96,13 @@ void gso_std_sort(uint32_t* keys, void* vals, uint32_t value_bytes, uint32_t n,
  * tree on `threads` host threads (keys only, u32 ascending). */
 void gso_std_sort_parallel(uint32_t* keys, uint32_t n, uint32_t threads);
 
+/* The defined result of a PAIRS sort as a permutation, for full-size parity tests: perm[j] = original index of
+ * the element the stable sort by key (GPUSortingCUDA/Sort/OneSweep.cu:346-600) puts at position j; descending =
+ * exact reverse (SortCommon.hlsl:594-597).  Sorted keys = keys[perm]; with payload = index the sorted payload IS
+ * perm.  Comparison sort of the distinct composites (bits << 32 | index) on `threads` host threads. */
+void gso_sort_permutation_parallel(const uint32_t* keys, uint32_t n, int key_type, int order, uint32_t threads,
+                                   uint32_t* perm);
+
 /* GPUSortingCUDA/UtilityKernels.cuh:402-479 and the order/type-aware form
  * GPUSortingD3D12/Shaders/Utility.hlsl:147-230: number of adjacent inversions
  * in keys (and, if vals != NULL and value_bytes==4, in vals reinterpreted as the key type). */

@@ -41,6 +41,8 @@ class Oracle:
         lib.gso_std_sort.restype = None
         lib.gso_std_sort_parallel.argtypes = [v, u32, u32]
         lib.gso_std_sort_parallel.restype = None
+        lib.gso_sort_permutation_parallel.argtypes = [v, u32, i, i, u32, v]
+        lib.gso_sort_permutation_parallel.restype = None
         lib.gso_validate.argtypes = [v, v, u32, u32, i, i]
         lib.gso_validate.restype = u32
         lib.gso_msd_splitters.argtypes = [v, u32, v]
@@ -98,6 +100,13 @@ class Oracle:
         k = keys.copy()
         self.lib.gso_std_sort_parallel(self._p(k), k.size, threads)
         return k
+
+    def sort_permutation_parallel(self, keys, key_type=KEY_U32, order=ASC, threads=None):
+        """perm[j] = original index of the element at sorted position j (stable by key; descending = reverse)."""
+        perm = np.empty(keys.size, dtype=np.uint32)
+        self.lib.gso_sort_permutation_parallel(self._p(keys), keys.size, key_type, order,
+                                               threads or self.hardware_threads(), self._p(perm))
+        return perm
 
     def validate(self, keys, key_type=KEY_U32, order=ASC, vals=None):
         return int(self.lib.gso_validate(self._p(keys), self._p(vals), self._vb(vals), keys.size, key_type, order))

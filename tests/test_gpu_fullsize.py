@@ -1,6 +1,10 @@
-"""GPU tests at BASELINE.json's full sizes: exact parity at 2^26 against the CPU
-oracle, size-independent properties at 2^28 (sortedness, permutation-invariant
-checksums, digit histograms preserved)."""
+"""GPU tests at BASELINE.json's full sizes: bit-exact parity at 2^28 against the CPU
+oracle for configs[1] (keys), configs[2] (u32 values) and configs[4] (u64 values, entropy
+presets 1 and 5) with value = original index (the only payload that exposes a stability
+violation), one exact case through the ballot ranking path at 2^26, plus size-independent
+properties (sortedness, permutation-invariant checksums, digit histograms preserved,
+idempotence) and the maximum size 2^30 - 1.
+Reference sizes: GPUSortingCUDA/Sort/OneSweepDispatcher.cuh:116-128,166-185 (2^26, 2^27, 2^28)."""
 import numpy as np
 import pytest
 
@@ -119,3 +123,69 @@ def test_2pow28_low_entropy_properties(gpu, andc, pairs):
     if pairs:  # the generator sets value = zero-extended key (UtilityKernels.cuh:157-168)
         assert bool(((dk.to(torch.int64) & 0xFFFFFFFF) == dv).all().item())
     s.close()
+
+
+# ---- bit-exact at the headline size ------------------------------------------------------------
+def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0):
+    """Sort 2^log2n generator keys (seed = log2n as the reference's big sizes, OneSweepDispatcher.cuh:116-128)
+    with value = original index and compare keys AND values element for element with the oracle's stable
+    order.  The comparison itself runs on the GPU (a gather and two equality reductions: plumbing)."""
+    import torch
+    n = 1 << log2n
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, log2n + 100 * andc, andc)
+    torch.cuda.synchronize()
+    keys = dk.cpu().numpy().view(np.uint32)
+    orig = dk.clone()
+    dv = None
+    if vb:
+        dv = torch.arange(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
+    s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
+    if rank_mode is not None:
+        s.set_rank_mode(rank_mode)
+    s.sort(dk, dv)
+    s.check()
+    if vb:
+        perm = oracle.sort_permutation_parallel(keys, kt, order)          # stable order by key (desc: its reverse)
+        dperm = torch.from_numpy(perm.view(np.int32)).cuda()
+        assert bool((dv.to(torch.int32) == dperm).all().item()), "payload order differs from the stable sort"
+        if vb == 8:
+            assert bool((dv >> 32 == 0).all().item())
+        idx = dperm.to(torch.int64) & 0xFFFFFFFF
+        del dperm
+        expect = orig[idx]
+        assert bool((dk == expect).all().item()), "sorted keys differ from the oracle"
+    else:
+        assert kt == 0 and order == 0
+        ref = oracle.std_sort_parallel(keys, oracle.hardware_threads())
+        assert bool((dk == torch.from_numpy(ref.view(np.int32)).cuda()).all().item()), "sorted keys differ from the oracle"
+    s.close()
+
+
+@pytest.mark.parametrize("andc", [0, 4])
+def test_2pow28_keys_exact_vs_oracle(gpu, oracle, andc):
+    """configs[1] bit-exact at full size; preset 5 runs the heavy-value position slices at their default
+    threshold (n >= 2^26, a value holding > n/2 keys)."""
+    _exact_case(gpu, oracle, 28, andc, 0)
+
+
+def test_2pow28_pairs_u32_index_exact_vs_oracle(gpu, oracle):
+    """configs[2] bit-exact with value = index: keys, and the stable payload order (1024 x 16 fused tiles)."""
+    _exact_case(gpu, oracle, 28, 0, 4)
+
+
+@pytest.mark.parametrize("andc", [0, 4])
+def test_2pow28_pairs_u64_index_exact_vs_oracle(gpu, oracle, andc):
+    """configs[4] bit-exact with value = index (u64), entropy presets 1 and 5 (512 x 32 tiles, late value fetch,
+    skewed ranking at preset 5)."""
+    _exact_case(gpu, oracle, 28, andc, 8)
+
+
+def test_2pow26_pairs_ballot_ranking_exact_vs_oracle(gpu, oracle):
+    """RANK 0 (64-lane ballot multi-split, the guaranteed path) at 2^26 with value = index."""
+    _exact_case(gpu, oracle, 26, 0, 4, rank_mode=0)
+
+
+def test_2pow27_pairs_descending_float_exact_vs_oracle(gpu, oracle):
+    """The reference's middle size (2^27) through typed keys + descending order with value = index."""
+    _exact_case(gpu, oracle, 27, 1, 4, order=1, kt=2)

@@ -43,9 +43,20 @@ def _gpu_sort(gpu, keys, kt=0, order=0, vals=None, max_keys=None):
     dv = None if vals is None else to_dev(vals)
     s.sort(dk, dv)
     s.check()
+    _assert_scan_state(s, keys.size)   # every sort of every test leaves the chained-scan state as it must be
     out = to_host(dk, np.uint32), (None if vals is None else to_host(dv, vals.dtype))
     s.close()
     return out
+
+
+def _assert_scan_state(s, n):
+    """gs_debug_check_state after a completed sort: every descriptor row INCLUSIVE and non-decreasing along its
+    chain, every chain's tickets >= its tiles, the histogram region handed back zeroed, and every pass that ran
+    accounts for exactly n keys (a dropped identity pass for none) — cf. UtilityKernels.cuh:482-502."""
+    r = s.check_state()
+    assert r["rows_not_inclusive"] == 0 and r["rows_not_monotone"] == 0, r
+    assert r["chains_short_of_tickets"] == 0 and r["hist_words_nonzero"] == 0, r
+    assert all(k in (0, n) for k in r["keys_per_pass"]), (n, r)
 
 
 def test_init_random_parity(gpu, oracle):
@@ -751,3 +762,33 @@ def test_two_host_threads_each_with_its_own_handle(gpu, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_scan_state_invariants(gpu, oracle):
+    """The slab-state checker itself: after tiled sorts of several shapes the report is clean and says which
+    passes ran (16-bit keys: two identity passes dropped); after a single-tile sort it is all zero; after a
+    stand-alone pass and after the histogram-only entry the histogram region is zero again."""
+    import torch
+    for n, andc, vb, mask in [(300000, 0, 0, 0xFFFFFFFF), (2500000, 0, 4, 0xFFFFFFFF), (1 << 22, 4, 0, 0xFFFFFFFF),
+                              (700001, 0, 8, 0x0000FFFF), (5000, 0, 0, 0xFFFFFFFF)]:
+        keys = oracle.init_random(n, 5 + andc, andc) & np.uint32(mask)
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        dk = to_dev(keys)
+        dv = None if not vb else torch.arange(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
+        s.sort(dk, dv)
+        s.check()
+        r = s.check_state()
+        assert (r["rows_not_inclusive"], r["rows_not_monotone"], r["chains_short_of_tickets"], r["hist_words_nonzero"]) == (0, 0, 0, 0), r
+        if n <= 8192:
+            assert r["keys_per_pass"] == [0, 0, 0, 0]          # single-tile path: no scan state
+        elif mask == 0x0000FFFF:
+            assert r["keys_per_pass"] == [n, n, 0, 0], r        # bytes 2 and 3 are constant: dropped as a pair
+        else:
+            assert r["keys_per_pass"] == [n, n, n, n], r
+        out = torch.empty_like(dk)
+        s.digit_pass(dk, out, 1, values_in=dv, values_out=None if dv is None else torch.empty_like(dv))
+        r = s.check_state()
+        assert r["hist_words_nonzero"] == 0 and r["rows_not_inclusive"] == 0 and r["keys_per_pass"][0] == n, r
+        s.global_histogram(dk)
+        assert s.check_state()["hist_words_nonzero"] == 0
+        s.close()

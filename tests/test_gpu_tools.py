@@ -1,0 +1,61 @@
+"""The C++ side of the boundary under test: the reference's own programs, compiled against the C++ mirrors of its
+dispatch surface (include/gpusort/*.hpp over the C-ABI), and the rocPRIM comparator, run as the driver would.
+
+  build/gpusorting_main         GPUSortingCUDA/GPUSortingCUDA.cu:16-40 (TestAll* + BatchTiming*)
+  build/gpusorting_d3d12_main   GPUSortingD3D12/Tests.h:6-186 (SuperTestOneSweep: 18 key x payload x order combinations)
+  build/rocprim_compare         the AMD analogue of GPUSortingCUDA/Sort/CubDispatcher.cuh:105-404
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tools(gpu):
+    """The binaries travel with the tree; (re)build whatever is missing or older than its sources."""
+    subprocess.check_call(["make", "-C", ROOT, "-s", "tools"])
+    return os.path.join(ROOT, "build")
+
+
+def _run(cmd, timeout=600):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    return p.returncode, p.stdout + p.stderr
+
+
+def test_reference_main_against_the_library(tools):
+    """`GPUSortingCUDA.cu` main(): TestAllKeysOnly / TestAllPairs ([P, 2P] ladder + 2^26, 2^27, 2^28 = P + 4 sorts each)
+    and the 2^28 batch timings, through OneSweepDispatcher.hpp.  Both halves must print 'All tests passed.'"""
+    rc, out = _run([os.path.join(tools, "gpusorting_main"), "28", "20"])
+    assert rc == 0, out[-2000:]
+    passed = re.findall(r"(\d+)/(\d+) All tests passed\.", out)
+    assert len(passed) == 2, out[-2000:]
+    for a, b in passed:
+        assert a == b and int(a) > 4096  # the whole ladder plus the three big sizes
+    rates = [float(x) for x in re.findall(r"Estimated speed at \d+ 32-bit elements: ([0-9.E+]+) keys/sec", out)]
+    assert len(rates) == 2 and rates[0] > 5e10 and rates[1] > 3e10, rates  # keys, pairs: far above any CPU or fallback rate
+    print(f"gpusorting_main 28 20: keys {rates[0]:.3e} keys/s, pairs {rates[1]:.3e} pairs/s")
+
+
+def test_d3d12_supertest_against_the_library(tools):
+    """`SuperTestOneSweep` (Tests.h:6-186): {asc, desc} x {uint32, int32, float32 keys} x {uint32, int32, float32 payloads}."""
+    rc, out = _run([os.path.join(tools, "gpusorting_d3d12_main"), "supertest"], timeout=900)
+    assert rc == 0, out[-2000:]
+    assert "18 / 18 ONESWEEP SUPER TEST PASSED!" in out, out[-2000:]
+
+
+def test_rocprim_comparator_sorts_and_agrees_elementwise(tools):
+    """The comparator (rocPRIM radix_sort_keys / _pairs, same generator and protocol) sorts, and on one 2^24 + 12345
+    case its output equals this library's output element for element (keys; pairs with value = index)."""
+    exe = os.path.join(tools, "rocprim_compare")
+    rc, out = _run([exe, "check", "24"])
+    assert rc == 0, out[-2000:]
+    assert out.count("identical=yes") == 2, out
+    rc, out = _run([exe, "26", "5"])
+    assert rc == 0, out[-2000:]
+    assert out.count("sorted=yes") == 2, out
+    print(out)

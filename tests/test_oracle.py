@@ -238,3 +238,16 @@ def test_oracle_matches_reference_kernels_run_here(oracle):
         rk, rv = oracle.std_sort(keys, 0, 0, np.arange(n, dtype=np.uint32))
         np.testing.assert_array_equal(k, rk, err_msg=f"pairs n={n}")
         np.testing.assert_array_equal(v, rv, err_msg=f"payload n={n}")
+
+
+@pytest.mark.parametrize("kt", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1])
+def test_sort_permutation_parallel_is_the_stable_sort(oracle, kt, order):
+    """The full-size parity tests take the stable order from the parallel composite sort: it must equal
+    std::stable_sort by key (descending: its exact reverse) — duplicates included (preset 4 keys)."""
+    n = 200003
+    keys = oracle.init_random(n, 11 + kt, 3)
+    perm = oracle.sort_permutation_parallel(keys, kt, order, threads=8)
+    rk, rv = oracle.std_sort(keys, kt, order, np.arange(n, dtype=np.uint32))
+    np.testing.assert_array_equal(perm, rv)
+    np.testing.assert_array_equal(keys[perm], rk)

@@ -2,6 +2,9 @@
 // GPUSortingCUDA/Sort/CubDispatcher.cuh:105-404): times rocprim::radix_sort_keys / _pairs on the
 // same generator, size and protocol as BatchTimingKeysOnly/Pairs.  NOT part of the product.
 // Usage: rocprim_compare [log2_size=28] [batch=20]
+//        rocprim_compare check [log2_size=24]   — sorts the same input with rocPRIM and with this library
+//        (keys; pairs with value = original index, both sorts are stable) and compares the outputs element for
+//        element on the device.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
@@ -14,7 +17,60 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+__global__ void iota_kernel(uint32_t* v, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+__global__ void diff_kernel(const uint32_t* a, const uint32_t* b, uint32_t n, unsigned long long* count) {
+    unsigned long long bad = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bad += a[i] != b[i];
+    if (bad) atomicAdd(count, bad);
+}
+
+// Same input through both sorters; returns 0 when every element agrees.
+static int check_identical(uint32_t lg) {
+    const uint32_t n = (1u << lg) + 12345u;  // not a multiple of any tile
+    uint32_t *keys, *kalt, *kin, *kout, *vals, *valt, *vin, *vout;
+    unsigned long long* d_bad;
+    for (uint32_t** p : {&keys, &kalt, &kin, &kout, &vals, &valt, &vin, &vout}) CK(hipMalloc(p, (size_t)n * 4));
+    CK(hipMalloc(&d_bad, 8));
+    int rc = 0;
+    for (int pairs = 0; pairs < 2; ++pairs) {
+        if (gs_init_random(kin, nullptr, 0u, pairs ? 2u : 0u, 77u + pairs, n, nullptr) != GS_OK) return 2;  // pairs: preset 3 (duplicates)
+        hipLaunchKernelGGL(iota_kernel, dim3(1024), dim3(256), 0, 0, vin, n);
+        CK(hipMemcpy(keys, kin, (size_t)n * 4, hipMemcpyDeviceToDevice));
+        CK(hipMemcpy(vals, vin, (size_t)n * 4, hipMemcpyDeviceToDevice));
+        size_t tmp_bytes = 0;
+        void* tmp = nullptr;
+        if (pairs) CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, n));
+        else CK(rocprim::radix_sort_keys(nullptr, tmp_bytes, kin, kout, n));
+        CK(hipMalloc(&tmp, tmp_bytes));
+        if (pairs) CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n));
+        else CK(rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n));
+        gs_onesweep* h = nullptr;
+        if (gs_onesweep_create(&h, n, pairs ? GS_MODE_PAIRS : GS_MODE_KEYS_ONLY, pairs ? 4u : 0u) != GS_OK) return 3;
+        const gs_status st = pairs ? gs_onesweep_sort_pairs(h, keys, vals, kalt, valt, n, GS_KEY_UINT32, GS_ORDER_ASCENDING, nullptr)
+                                   : gs_onesweep_sort_keys(h, keys, kalt, n, GS_KEY_UINT32, GS_ORDER_ASCENDING, nullptr);
+        if (st != GS_OK || gs_onesweep_check(h, nullptr) != GS_OK) return 4;
+        unsigned long long bad_k = 0, bad_v = 0;
+        CK(hipMemset(d_bad, 0, 8));
+        hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, keys, kout, n, d_bad);
+        CK(hipMemcpy(&bad_k, d_bad, 8, hipMemcpyDeviceToHost));
+        if (pairs) {
+            CK(hipMemset(d_bad, 0, 8));
+            hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, vals, vout, n, d_bad);
+            CK(hipMemcpy(&bad_v, d_bad, 8, hipMemcpyDeviceToHost));
+        }
+        printf("check %s n=%u: gpusort vs rocprim  key mismatches=%llu  value mismatches=%llu  identical=%s\n", pairs ? "pairs" : "keys ", n,
+               bad_k, bad_v, (bad_k | bad_v) == 0 ? "yes" : "NO");
+        rc |= (bad_k | bad_v) != 0;
+        gs_onesweep_destroy(h);
+        CK(hipFree(tmp));
+    }
+    return rc;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "check")) return check_identical(argc > 2 ? (uint32_t)atoi(argv[2]) : 24u);
     const uint32_t lg = argc > 1 ? (uint32_t)atoi(argv[1]) : 28u;
     const uint32_t batch = argc > 2 ? (uint32_t)atoi(argv[2]) : 20u;
     const uint32_t n = 1u << lg;

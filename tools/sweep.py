@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpusorting_amd as g  # noqa: E402
 from gpusorting_amd import _lib  # noqa: E402
 
-SHAPES = [(512, 32), (1024, 16), (512, 16), (256, 32), (256, 16)]
+SHAPES = [(512, 32), (512, 20), (1024, 16), (512, 16), (256, 32), (256, 16)]
 
 
 def timed(fn, reps=10):
