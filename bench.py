@@ -308,6 +308,35 @@ def main():
         nonempty = [r for r in rows if r[0]]
         total_ok = total_ok and all(a[2] <= b[1] for a, b in zip(nonempty[:-1], nonempty[1:]))
 
+    # ---- multi-GPU: phase times of the last step on every rank (HIP events inside gs_onesweep_sort_sharded),
+    # bytes exchanged, and the exchange rate per xGMI link against its peak ----
+    mgpu = None
+    if dist is not None:
+        p = sharded.profile()
+        mine = torch.tensor([p["split_ms"], p["exchange_ms"], p["local_sort_ms"], p["total_ms"], float(p["bytes_sent"]),
+                             float(p["bytes_received"]), float(out_n)], dtype=torch.float64, device=coll_dev)
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        rows = [x.tolist() for x in allp]
+        mx = [max(r[i] for r in rows) for i in range(4)]
+        sent = [r[4] for r in rows]
+        link_peak = 153.0  # GB/s per xGMI link, 7 links per GPU (task statement / BASELINE.md multi-GPU anchor)
+        ex_s = mx[1] * 1e-3
+        per_rank_gbs = max(sent) / ex_s / 1e9 if ex_s > 0 else 0.0
+        mgpu = {
+            "pipeline": "gs_onesweep_sort_sharded (C++ over RCCL): histogram + all-gather + device plan + partition pass | "
+                        "one group of send/recv pairs | local 4-pass OneSweep",
+            "phase_ms_max_over_ranks": {"split": mx[0], "exchange": mx[1], "local_sort": mx[2], "total": mx[3]},
+            "phase_ms_rank0": {"split": rows[0][0], "exchange": rows[0][1], "local_sort": rows[0][2], "total": rows[0][3]},
+            "bytes_sent_off_rank": {"max": max(sent), "min": min(sent), "sum": sum(sent)},
+            "bucket_keys": {"max": max(r[6] for r in rows), "min": min(r[6] for r in rows)},
+            "exchange_GBps_per_rank": per_rank_gbs,
+            "exchange_GBps_per_link": per_rank_gbs / max(world - 1, 1),
+            "xgmi_link_peak_GBps": link_peak, "links_used_per_rank": world - 1,
+            "frac_of_link_peak": per_rank_gbs / max(world - 1, 1) / link_peak,
+            "split": sharded.last_split,
+        }
+
     # ---- per-kernel HIP-event profile of the local 4-pass sort (dominant kernel roofline) ----
     prof_sorter = sorter
     prof = None
@@ -348,15 +377,17 @@ def main():
         "config": {
             "workload": (f"2^{args.log2_keys} uniform-random uint32 {'pairs' if pairs else 'keys-only'} OneSweep, 1 MI355X "
                          f"(BASELINE configs[{2 if args.pairs == 4 else 4 if args.pairs == 8 else 1}])") if world == 1 else
-                        (f"2^{args.log2_keys} uint32 keys per GPU x {world} GPUs: MSD split + RCCL all-to-all-v + per-GPU "
+                        (f"2^{args.log2_keys} uint32 keys per GPU x {world} GPUs: MSD split + RCCL bucket exchange + per-GPU "
                          f"OneSweep (BASELINE configs[3] shape, weak scaling)"),
             "timed_region": "whole sort per step: GlobalHistogram (incl. the state clear) + Scan + 4 DigitBinningPass"
-                            + ("" if world == 1 else ", after the top-byte split + all-to-all-v exchange of the step"),
+                            + ("" if world == 1 else ", after the top-byte split + bucket exchange of the step (all inside the timed region)"),
             "keys_per_gpu": n, "entropy_preset": args.entropy + 1, "generator": "InitRandom seed 10+i (+1000*rank)",
             "tile_keys": sorter.partition_size, "verified_sorted": bool(sorted_ok and total_ok),
         },
         "roofline": roofline_block(n, args.pairs, prof, pmc_traffic(args.log2_keys, args.pairs, args.entropy, args.shape, sorter.partition_size)),
     }
+    if mgpu is not None:
+        out["multi_gpu"] = mgpu
     if world == 1 and not args.pairs and not args.entropy and not args.shape and not args.no_more:
         # free the headline's buffers first: the block allocates its own
         bufs.clear()

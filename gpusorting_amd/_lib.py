@@ -13,12 +13,24 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPUSORT_LIB") or os.path.join(_HERE, "lib", "libgpusort.so")  # env: ablation builds
 
-GS_OK, GS_ERR_ARG, GS_ERR_SIZE, GS_ERR_HIP, GS_ERR_TIMEOUT, GS_ERR_MODE, GS_ERR_NO_DEVICE = range(7)
+GS_OK, GS_ERR_ARG, GS_ERR_SIZE, GS_ERR_HIP, GS_ERR_TIMEOUT, GS_ERR_MODE, GS_ERR_NO_DEVICE, GS_ERR_COMM = range(8)
+GS_MGPU_UNIQUE_ID_BYTES = 128
 GS_MAX_KEYS = (1 << 30) - 1
 GS_PROFILE_SLOTS = 8
 
 # every symbol include/gpusort.h declares: (name, restype, argtypes)
 _u32, _vp, _int = C.c_uint32, C.c_void_p, C.c_int
+_u32p, _u64p, _u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+
+# gs_mgpu_transport (include/gpusort.h): the two functions a transport provides
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp), _u32p, _u32p, _u32p, _u32p, _u32p, _vp)
+
+
+class MgpuTransport(C.Structure):
+    _fields_ = [("user", _vp), ("all_gather_u32", ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
+
+
 _PROTOS = [
     ("gs_version", C.c_char_p, []),
     ("gs_status_string", C.c_char_p, [_int]),
@@ -50,6 +62,18 @@ _PROTOS = [
     ("gs_msd_splitters", _int, [C.POINTER(C.c_uint64), _u32, C.POINTER(_u32)]),
     ("gs_msd_splitters_n", _int, [C.POINTER(C.c_uint64), _u32, _u32, C.POINTER(_u32)]),
     ("gs_onesweep_msd_fine_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
+    ("gs_mgpu_get_unique_id", _int, [_u8p]),
+    ("gs_mgpu_create", _int, [C.POINTER(_vp), _u8p, _u32, _u32, _u32, _u32, _int, _u32]),
+    ("gs_mgpu_destroy", _int, [_vp]),
+    ("gs_onesweep_sort_sharded", _int, [_vp, _vp, _vp, _u32, _int, _vp, _vp, _u32p, _vp]),
+    ("gs_mgpu_get_profile", _int, [_vp, C.POINTER(C.c_float), _u64p, _u64p, _u32p]),
+    ("gs_mgpu_last_plan", _int, [_vp, _u32p, _u32]),
+    ("gs_mgpu_sorter", _vp, [_vp]),
+    ("gs_mgpu_set_force_exchange", _int, [_vp, _int]),
+    ("gs_last_rccl_error", _int, []),
+    ("gs_mgpu_create_with_transport", _int, [C.POINTER(_vp), C.POINTER(MgpuTransport), _u32, _u32, _u32, _u32, _int, _u32]),
+    ("gs_msd_plan", _int, [_u32p, _u32, _u32, _u32, _u32, _u32p]),
+    ("gs_debug_msd_plan_device", _int, [_u32p, _u32, _u32, _u32, _u32, _u32p, _vp]),
 ]
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOS]
 
@@ -62,6 +86,8 @@ class GpuSortError(RuntimeError):
         msg = load().gs_status_string(status).decode()
         if status == GS_ERR_HIP:
             msg += f" (hipError {load().gs_last_hip_error()})"
+        if status == GS_ERR_COMM:
+            msg += f" (ncclResult {load().gs_last_rccl_error()})"
         super().__init__(f"{where}: {msg} [gs_status {status}]")
 
 

@@ -298,6 +298,7 @@ const char* gs_status_string(gs_status s) {
         case GS_ERR_TIMEOUT: return "look-back timeout on device";
         case GS_ERR_MODE: return "mode / value width mismatch";
         case GS_ERR_NO_DEVICE: return "no GPU device";
+        case GS_ERR_COMM: return "multi-GPU communication (RCCL) error";
     }
     return "unknown";
 }
@@ -728,3 +729,5 @@ gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uin
 }
 
 }  // extern "C"
+
+#include "gpusort_mgpu.hpp"

@@ -1,0 +1,445 @@
+// gpusort_mgpu.hpp — multi-GPU sharded sort behind the C-ABI (include/gpusort.h, "multi-GPU" section); part of
+// the gpusort_capi.hip translation unit (it drives the handle's internals: prologue, pass launchers, sort_impl).
+//
+// One process per GPU.  BASELINE.json configs[3]: "MSD bucket split + RCCL Alltoallv across 8 MI355X then per-GPU
+// OneSweep"; the reference has no multi-GPU code.  Pipeline of gs_onesweep_sort_sharded, everything
+// enqueued on the caller's stream:
+//   1. GlobalHistogram + Scan of the shard on its top byte (the sort's own kernels, position-segment chains),
+//      folded to 256 counts on the device
+//   2. all-gather of the 256 counts (RCCL ncclAllGather over xGMI)
+//   3. msd_plan_kernel: splitters, per-peer send/receive counts, overflow check — on the device
+//   4. ONE small device-to-host copy (the plan: a few dozen words) and ONE event wait: RCCL's send/recv take their
+//      counts as host integers, so this wait is inherent in the exchange, and it is the only one
+//   5. the stable DigitBinningPass on the top byte groups the shard by destination (reusing the scan state of 1)
+//   6. bucket exchange: ONE ncclGroup of send/recv pairs for keys and values together — point-to-point on all
+//      xGMI links at once
+//   7. the local 4-pass OneSweep on the received bucket, in the caller's output buffers
+// Skewed shards (a top-byte bucket would not fit a rank): the split is redone at the 12-bit prefix (4096 bins, shard
+// ordered by its top two bytes); if that does not fit either, every rank returns GS_ERR_SIZE together.
+// RCCL is loaded lazily (dlopen "librccl.so.1") so that single-GPU users of libgpusort.so do not need it; tests
+// inject a host-staged transport (gs_mgpu_create_with_transport) to run several ranks on one GPU.
+#include <dlfcn.h>
+
+#include <vector>
+
+#include "msd_kernels.hpp"
+
+namespace {
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;  // ncclUniqueId (rccl.h:40-43)
+    int (*GetUniqueId)(UniqueId*);
+    int (*CommInitRank)(void** comm, int nranks, UniqueId id, int rank);
+    int (*CommDestroy)(void* comm);
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
+    int (*Send)(const void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t s);
+    int (*Recv)(void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t s);
+    int (*GroupStart)();
+    int (*GroupEnd)();
+    const char* (*GetErrorString)(int);
+    bool ok;
+};
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3;  // ncclDataType_t (rccl.h:460-464)
+static_assert(GS_MGPU_UNIQUE_ID_BYTES == 128, "ncclUniqueId is 128 bytes");
+
+Rccl* rccl() {
+    static Rccl r = [] {
+        Rccl x{};
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return x;
+#define GS_SYM(field, name) x.field = reinterpret_cast<decltype(x.field)>(dlsym(h, name))
+        GS_SYM(GetUniqueId, "ncclGetUniqueId");
+        GS_SYM(CommInitRank, "ncclCommInitRank");
+        GS_SYM(CommDestroy, "ncclCommDestroy");
+        GS_SYM(AllGather, "ncclAllGather");
+        GS_SYM(Send, "ncclSend");
+        GS_SYM(Recv, "ncclRecv");
+        GS_SYM(GroupStart, "ncclGroupStart");
+        GS_SYM(GroupEnd, "ncclGroupEnd");
+        GS_SYM(GetErrorString, "ncclGetErrorString");
+#undef GS_SYM
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.Send && x.Recv && x.GroupStart && x.GroupEnd;
+        return x;
+    }();
+    return r.ok ? &r : nullptr;
+}
+
+thread_local int g_last_rccl_error = 0;
+
+struct RcclTransport {
+    void* comm;
+    uint32_t rank, world;
+};
+
+int rccl_all_gather_u32(void* user, const void* d_send, void* d_recv, size_t count, void* stream) {
+    RcclTransport* t = static_cast<RcclTransport*>(user);
+    const int e = rccl()->AllGather(d_send, d_recv, count, kNcclUint32, t->comm, static_cast<hipStream_t>(stream));
+    if (e) g_last_rccl_error = e;
+    return e;
+}
+
+// keys and values in ONE group: every (array, peer) pair is a send and a receive that progress together
+int rccl_exchange(void* user, uint32_t n_arrays, const void* const* d_send, void* const* d_recv, const uint32_t* elem_bytes,
+                  const uint32_t* send_counts, const uint32_t* send_displs, const uint32_t* recv_counts,
+                  const uint32_t* recv_displs, void* stream) {
+    RcclTransport* t = static_cast<RcclTransport*>(user);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Rccl* r = rccl();
+    for (uint32_t a = 0; a < n_arrays; ++a) {  // own bucket: a copy inside the device
+        const size_t eb = elem_bytes[a];
+        if (send_counts[t->rank] &&
+            hipMemcpyAsync(static_cast<char*>(d_recv[a]) + (size_t)recv_displs[t->rank] * eb,
+                           static_cast<const char*>(d_send[a]) + (size_t)send_displs[t->rank] * eb,
+                           (size_t)send_counts[t->rank] * eb, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return -1;
+    }
+    if (t->world == 1) return 0;
+    int e = r->GroupStart();
+    for (uint32_t a = 0; a < n_arrays && !e; ++a) {
+        const size_t eb = elem_bytes[a];
+        for (uint32_t p = 0; p < t->world && !e; ++p) {
+            if (p == t->rank) continue;
+            if (send_counts[p])
+                e = r->Send(static_cast<const char*>(d_send[a]) + (size_t)send_displs[p] * eb, (size_t)send_counts[p] * eb, kNcclUint8,
+                            (int)p, t->comm, s);
+            if (!e && recv_counts[p])
+                e = r->Recv(static_cast<char*>(d_recv[a]) + (size_t)recv_displs[p] * eb, (size_t)recv_counts[p] * eb, kNcclUint8, (int)p,
+                            t->comm, s);
+        }
+    }
+    const int e2 = r->GroupEnd();
+    if (e || e2) g_last_rccl_error = e ? e : e2;
+    return e ? e : e2;
+}
+
+}  // namespace
+
+struct gs_mgpu {
+    uint32_t rank, world, shard_keys, capacity, value_bytes;
+    gs_mode mode;
+    gs_onesweep* sorter;       // local engine: scan state for `capacity` keys
+    gs_mgpu_transport transport;
+    RcclTransport rccl_state;  // when the transport is RCCL
+    bool owns_comm;
+    uint32_t *part_keys;       // shard grouped by destination; alt buffer of the local sort afterwards
+    void* part_vals;
+    uint32_t *d_hist, *d_table, *d_plan;  // nbins, world x nbins, plan words
+    uint32_t* h_plan;          // pinned mirror of the plan
+    hipEvent_t ev_plan, ev[5];
+    int force_exchange;        // run split + exchange even with one rank (tests)
+    float last_ms[4];
+    uint64_t last_sent, last_recv;
+    uint32_t last_fine;
+    bool prof_pending;
+};
+
+namespace {
+
+gs_status mgpu_alloc(gs_mgpu* c) {
+    const size_t scratch = c->shard_keys > c->capacity ? c->shard_keys : c->capacity;
+    GS_HIP(hipMalloc(&c->part_keys, scratch * sizeof(uint32_t)));
+    if (c->value_bytes) GS_HIP(hipMalloc(&c->part_vals, scratch * (size_t)c->value_bytes));
+    GS_HIP(hipMalloc(&c->d_hist, 4096 * sizeof(uint32_t)));
+    GS_HIP(hipMalloc(&c->d_table, (size_t)c->world * 4096 * sizeof(uint32_t)));
+    GS_HIP(hipMalloc(&c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t)));
+    GS_HIP(hipHostMalloc(&c->h_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipHostMallocDefault));
+    GS_HIP(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+    for (auto& e : c->ev) GS_HIP(hipEventCreate(&e));
+    return GS_OK;
+}
+
+gs_status mgpu_new(gs_mgpu** out, uint32_t rank, uint32_t world, uint32_t shard_keys, uint32_t capacity, gs_mode mode,
+                   uint32_t value_bytes) {
+    if (!out) return GS_ERR_ARG;
+    *out = nullptr;
+    if (world == 0 || world > gs::MSD_MAX_WORLD || rank >= world) return GS_ERR_ARG;
+    if (shard_keys == 0 || shard_keys > GS_MAX_KEYS || capacity < shard_keys || capacity > GS_MAX_KEYS) return GS_ERR_SIZE;
+    gs_mgpu* c = new (std::nothrow) gs_mgpu();
+    if (!c) return GS_ERR_ARG;
+    c->rank = rank; c->world = world; c->shard_keys = shard_keys; c->capacity = capacity;
+    c->mode = mode; c->value_bytes = mode == GS_MODE_PAIRS ? value_bytes : 0;
+    c->force_exchange = 0;
+    if (const char* env = getenv("GPUSORT_MGPU_FORCE_EXCHANGE")) c->force_exchange = atoi(env) ? 1 : 0;
+    gs_status st = gs_onesweep_create(&c->sorter, capacity, mode, value_bytes);
+    if (st == GS_OK) st = mgpu_alloc(c);
+    if (st != GS_OK) { gs_mgpu_destroy(c); return st; }
+    *out = c;
+    return GS_OK;
+}
+
+// steps 1-4 for one granularity: histogram of the shard -> gathered table -> plan on the host.  fine = 12-bit prefix.
+gs_status mgpu_plan(gs_mgpu* c, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, bool fine, PassPlan* pp) {
+    gs_onesweep* h = c->sorter;
+    const uint32_t nbins = fine ? 4096u : gs::RADIX;
+    gs_status st = fine ? prologue(h, d_keys, n, kt, s, 2, 2, pp) : prologue(h, d_keys, n, kt, s, 3, 1, pp);
+    if (st != GS_OK) return st;
+    hipLaunchKernelGGL(gs::msd_fold_kernel, dim3(nbins / 256), dim3(256), 0, s, h->slab + SLAB_HIST, nbins, c->d_hist);
+    if (fine) {  // no pass follows this prologue: hand HIST back zeroed
+        GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
+        h->hist_dirty = false;
+    }
+    if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, nbins, s) != 0) return GS_ERR_COMM;
+    hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, nbins, c->world, c->rank, c->capacity, c->d_plan);
+    GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipEventRecord(c->ev_plan, s));
+    GS_HIP(hipEventSynchronize(c->ev_plan));  // the ONE host wait of the pipeline: send/recv counts are host integers
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gs_last_rccl_error(void) { return g_last_rccl_error; }
+
+gs_status gs_mgpu_get_unique_id(uint8_t id[GS_MGPU_UNIQUE_ID_BYTES]) {
+    if (!id) return GS_ERR_ARG;
+    Rccl* r = rccl();
+    if (!r) return GS_ERR_COMM;
+    Rccl::UniqueId u;
+    const int e = r->GetUniqueId(&u);
+    if (e) { g_last_rccl_error = e; return GS_ERR_COMM; }
+    memcpy(id, u.internal, GS_MGPU_UNIQUE_ID_BYTES);
+    return GS_OK;
+}
+
+gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
+                         uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes) {
+    if (!id) return GS_ERR_ARG;
+    Rccl* r = rccl();
+    if (!r) return GS_ERR_COMM;
+    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes);
+    if (st != GS_OK) return st;
+    gs_mgpu* c = *out;
+    Rccl::UniqueId u;
+    memcpy(u.internal, id, GS_MGPU_UNIQUE_ID_BYTES);
+    void* comm = nullptr;
+    const int e = r->CommInitRank(&comm, (int)world, u, (int)rank);  // collective: every rank of the job is in here
+    if (e) {
+        g_last_rccl_error = e;
+        gs_mgpu_destroy(c);
+        *out = nullptr;
+        return GS_ERR_COMM;
+    }
+    c->rccl_state = RcclTransport{comm, rank, world};
+    c->owns_comm = true;
+    c->transport = gs_mgpu_transport{&c->rccl_state, rccl_all_gather_u32, rccl_exchange};
+    return GS_OK;
+}
+
+gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* t, uint32_t rank, uint32_t world,
+                                        uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes) {
+    if (!t || !t->all_gather_u32 || !t->exchange) return GS_ERR_ARG;
+    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes);
+    if (st != GS_OK) return st;
+    (*out)->transport = *t;
+    (*out)->owns_comm = false;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_destroy(gs_mgpu* c) {
+    if (!c) return GS_ERR_ARG;
+    if (c->owns_comm && c->rccl_state.comm && rccl()) (void)rccl()->CommDestroy(c->rccl_state.comm);
+    if (c->sorter) (void)gs_onesweep_destroy(c->sorter);
+    if (c->part_keys) (void)hipFree(c->part_keys);
+    if (c->part_vals) (void)hipFree(c->part_vals);
+    if (c->d_hist) (void)hipFree(c->d_hist);
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_plan) (void)hipFree(c->d_plan);
+    if (c->h_plan) (void)hipHostFree(c->h_plan);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+    return GS_OK;
+}
+
+gs_onesweep* gs_mgpu_sorter(gs_mgpu* c) { return c ? c->sorter : nullptr; }
+
+gs_status gs_mgpu_set_force_exchange(gs_mgpu* c, int on) {
+    if (!c) return GS_ERR_ARG;
+    c->force_exchange = on ? 1 : 0;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d_vals, uint32_t n, gs_key_type kt,
+                                   void* d_out_keys, void* d_out_vals, uint32_t* out_n, void* stream) {
+    if (!c || !d_keys || !d_out_keys || !out_n || misaligned(d_keys) || misaligned(d_out_keys)) return GS_ERR_ARG;
+    if ((int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n > c->shard_keys) return GS_ERR_SIZE;
+    const uint32_t vb = c->value_bytes;
+    if (vb) {
+        if (!d_vals || !d_out_vals || misaligned(d_vals) || misaligned(d_out_vals)) return GS_ERR_ARG;
+    } else if (d_vals || d_out_vals) {
+        return GS_ERR_MODE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    gs_onesweep* h = c->sorter;
+    *out_n = 0;
+    c->prof_pending = false;
+    c->last_sent = c->last_recv = 0;
+    c->last_fine = 0;
+    GS_HIP(hipEventRecord(c->ev[0], s));
+    uint32_t n_recv = n;
+    if (c->world == 1 && !c->force_exchange) {
+        if (n) GS_HIP(hipMemcpyAsync(d_out_keys, d_keys, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (n && vb) GS_HIP(hipMemcpyAsync(d_out_vals, d_vals, (size_t)n * vb, hipMemcpyDeviceToDevice, s));
+        GS_HIP(hipEventRecord(c->ev[1], s));
+        GS_HIP(hipEventRecord(c->ev[2], s));
+    } else {
+        // An empty shard still takes part in every collective; the kernels need n >= 1, so an empty shard
+        // contributes a zero histogram directly.
+        PassPlan pp{};
+        bool fine = false;
+        if (n == 0) {
+            GS_HIP(hipMemsetAsync(c->d_hist, 0, 4096 * sizeof(uint32_t), s));
+            if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, gs::RADIX, s) != 0) return GS_ERR_COMM;
+            hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, gs::RADIX, c->world, c->rank, c->capacity, c->d_plan);
+            GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            GS_HIP(hipEventRecord(c->ev_plan, s));
+            GS_HIP(hipEventSynchronize(c->ev_plan));
+        } else {
+            gs_status st = mgpu_plan(c, d_keys, n, kt, s, false, &pp);
+            if (st != GS_OK) return st;
+        }
+        if (c->h_plan[gs::PLAN_OVERFLOW]) {
+            // every rank sees the same gathered table and takes the same decision: split at the 12-bit prefix
+            fine = true;
+            if (n) {  // the top-byte scan state is abandoned: its histogram region must be handed back zeroed
+                GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
+                h->hist_dirty = false;
+                gs_status st = mgpu_plan(c, d_keys, n, kt, s, true, &pp);
+                if (st != GS_OK) return st;
+            } else {
+                if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, 4096, s) != 0) return GS_ERR_COMM;
+                hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, 4096u, c->world, c->rank, c->capacity, c->d_plan);
+                GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                GS_HIP(hipEventRecord(c->ev_plan, s));
+                GS_HIP(hipEventSynchronize(c->ev_plan));
+            }
+            if (c->h_plan[gs::PLAN_OVERFLOW]) return GS_ERR_SIZE;  // on every rank alike: raise the capacity
+        }
+        c->last_fine = fine ? 1u : 0u;
+        const uint32_t W = c->world;
+        const uint32_t* send = c->h_plan + gs::PLAN_HEADER;
+        const uint32_t* recv = send + W;
+        n_recv = c->h_plan[gs::PLAN_NRECV];
+        if (n_recv > c->capacity) return GS_ERR_SIZE;
+        // group the shard by destination (stable)
+        if (n) {
+            const BinLauncher fn = g_shapes[h->shape].fn[h->rank_mode][vb_index(vb)][kt];
+            if (!fn) return GS_ERR_ARG;
+            if (!fine) {
+                fn(s, pp.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys)), c->part_keys, const_cast<void*>(d_vals),
+                   c->part_vals, h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB,
+                   h->slab + SLAB_STATUS, n, 24, 4u);
+                GS_HIP(hipGetLastError());
+                h->hist_dirty = false;
+            } else {  // order by the top two bytes: every 12-bit prefix range is contiguous (the output buffers are the scratch)
+                gs_status st = gs_onesweep_digit_pass(h, d_keys, d_out_keys, d_vals, d_out_vals, n, 2, kt, 0, s);
+                if (st == GS_OK) st = gs_onesweep_digit_pass(h, d_out_keys, c->part_keys, d_out_vals, c->part_vals, n, 3, kt, 0, s);
+                if (st != GS_OK) return st;
+            }
+        }
+        GS_HIP(hipEventRecord(c->ev[1], s));
+        // bucket exchange: keys and values in one group
+        std::vector<uint32_t> sd(W), rd(W);
+        uint32_t a = 0, b = 0;
+        for (uint32_t p = 0; p < W; ++p) {
+            sd[p] = a; rd[p] = b;
+            a += send[p]; b += recv[p];
+            if (p != c->rank) { c->last_sent += (uint64_t)send[p] * (4 + vb); c->last_recv += (uint64_t)recv[p] * (4 + vb); }
+        }
+        const void* src[2] = {c->part_keys, c->part_vals};
+        void* dst[2] = {d_out_keys, d_out_vals};
+        const uint32_t eb[2] = {4u, vb};
+        if (c->transport.exchange(c->transport.user, vb ? 2u : 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) return GS_ERR_COMM;
+        GS_HIP(hipEventRecord(c->ev[2], s));
+    }
+    // local 4-pass sort of the received bucket; the partition buffers are free again and serve as alt
+    if (n_recv) {
+        gs_status st = vb ? gs_onesweep_sort_pairs(h, d_out_keys, d_out_vals, c->part_keys, c->part_vals, n_recv, kt, GS_ORDER_ASCENDING, s)
+                          : gs_onesweep_sort_keys(h, d_out_keys, c->part_keys, n_recv, kt, GS_ORDER_ASCENDING, s);
+        if (st != GS_OK) return st;
+    }
+    GS_HIP(hipEventRecord(c->ev[3], s));
+    *out_n = n_recv;
+    c->prof_pending = true;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_get_profile(gs_mgpu* c, float ms[4], uint64_t* bytes_sent, uint64_t* bytes_received, uint32_t* fine_split) {
+    if (!c || !ms || !c->prof_pending) return GS_ERR_ARG;
+    GS_HIP(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; ++i) GS_HIP(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms[3], c->ev[0], c->ev[3]));
+    if (bytes_sent) *bytes_sent = c->last_sent;
+    if (bytes_received) *bytes_received = c->last_recv;
+    if (fine_split) *fine_split = c->last_fine;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_last_plan(gs_mgpu* c, uint32_t* plan, uint32_t words) {
+    if (!c || !plan || words < gs::plan_words(c->world)) return GS_ERR_ARG;
+    memcpy(plan, c->h_plan, gs::plan_words(c->world) * sizeof(uint32_t));
+    return GS_OK;
+}
+
+gs_status gs_msd_plan(const uint32_t* table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity, uint32_t* plan) {
+    if (!table || !plan || nbins == 0 || world == 0 || world > nbins || rank >= world) return GS_ERR_ARG;
+    std::vector<uint64_t> g(nbins, 0);
+    for (uint32_t r = 0; r < world; ++r)
+        for (uint32_t b = 0; b < nbins; ++b) g[b] += table[(size_t)r * nbins + b];
+    uint32_t* send = plan + gs::PLAN_HEADER;
+    uint32_t* recv = send + world;
+    uint32_t* first = recv + world;
+    gs_status st = gs_msd_splitters_n(g.data(), nbins, world, first);
+    if (st != GS_OK) return st;
+    uint64_t nrecv = 0, mx = 0;
+    for (uint32_t d = 0; d < world; ++d) {
+        uint64_t bucket = 0;
+        uint32_t mine = 0;
+        for (uint32_t b = first[d]; b < first[d + 1]; ++b) {
+            bucket += g[b];
+            mine += table[(size_t)rank * nbins + b];
+        }
+        send[d] = mine;
+        mx = bucket > mx ? bucket : mx;
+    }
+    for (uint32_t q = 0; q < world; ++q) {
+        uint32_t c = 0;
+        for (uint32_t b = first[rank]; b < first[rank + 1]; ++b) c += table[(size_t)q * nbins + b];
+        recv[q] = c;
+        nrecv += c;
+    }
+    plan[gs::PLAN_NRECV] = (uint32_t)(nrecv > 0xffffffffull ? 0xffffffffull : nrecv);
+    plan[gs::PLAN_OVERFLOW] = mx > capacity ? 1u : 0u;
+    plan[gs::PLAN_MAXBUCKET] = (uint32_t)(mx > 0xffffffffull ? 0xffffffffull : mx);
+    plan[3] = 0;
+    return GS_OK;
+}
+
+gs_status gs_debug_msd_plan_device(const uint32_t* h_table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity,
+                                   uint32_t* h_plan, void* stream) {
+    if (!h_table || !h_plan || (nbins != 256 && nbins != 4096) || world == 0 || world > gs::MSD_MAX_WORLD || rank >= world) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t *d_t = nullptr, *d_p = nullptr;
+    GS_HIP(hipMalloc(&d_t, (size_t)world * nbins * 4));
+    gs_status ret = GS_OK;
+    if (hipMalloc(&d_p, gs::plan_words(world) * 4) != hipSuccess) ret = GS_ERR_HIP;
+    if (ret == GS_OK && hipMemcpyAsync(d_t, h_table, (size_t)world * nbins * 4, hipMemcpyHostToDevice, s) != hipSuccess) ret = GS_ERR_HIP;
+    if (ret == GS_OK) {
+        hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, d_t, nbins, world, rank, capacity, d_p);
+        if (hipMemcpyAsync(h_plan, d_p, gs::plan_words(world) * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            ret = GS_ERR_HIP;
+    }
+    (void)hipFree(d_t);
+    if (d_p) (void)hipFree(d_p);
+    return ret;
+}
+
+}  // extern "C"

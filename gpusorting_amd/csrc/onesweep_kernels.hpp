@@ -107,8 +107,14 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 #ifndef GS_FUSED_PAIRS
 #define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
 #endif
+#ifndef GS_WALK_ROWS
+#define GS_WALK_ROWS 1  // descriptor rows per round trip of the look-back walk.  Measured in round 2 (profiles/
+                        // r02_ab_early_lookback_rows.txt): 4 rows per trip +3 %; 4 / 8 / 16 rows requested BEFORE the
+                        // staging phase and consumed after it +3 / +5 / +6 % — an INCLUSIVE row is further back than that
+                        // when the request is issued, so the walk repeats the reads and the chip only moved more bytes
+#endif
 #ifndef GS_ONEWAVE_REDUCE
-#define GS_ONEWAVE_REDUCE 1  // the per-tile digit fold (prefix over waves, totals, 256-digit scan) by one wave on 16-byte LDS accesses
+#define GS_ONEWAVE_REDUCE 0  // (measured: no gain over the four-wave form, profiles/r02_ab_onewave_exp1.txt) 1 = the per-tile digit fold (prefix over waves, totals, 256-digit scan) by one wave on 16-byte LDS accesses
 #endif
 #ifndef GS_HEAVY_SHARE
 #define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
@@ -167,9 +173,16 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_DESC % 4 == 0, "r
 #ifndef GS_HIST_SKEW_LANES
 #define GS_HIST_SKEW_LANES 8  // lanes sharing the first lane's bin that switch a byte's counting to wave-aggregated adds
 #endif
+#ifndef GS_HIST_PROBE
+#define GS_HIST_PROBE 1  // 0 (ablation): no skew probe, plain adds only
+#endif
 #ifndef GS_HIST_UNROLL
 #define GS_HIST_UNROLL 4
 #endif
+#ifndef GS_HIST_REPLICAS
+#define GS_HIST_REPLICAS 1  // pass-0 digit counts on 32 lane-private, bank-conflict-free replicas (see global_histogram_kernel)
+#endif
+constexpr uint32_t HIST_FOLD_CHUNKS = 256;  // replicas are folded at least this often (16-bit counters, 128 keys per replica per chunk)
 constexpr uint32_t HIST_CHUNK = 4 * GS_GHIST_THREADS;  // keys per histogram work item (4 per thread); position segments are multiples of it
 
 enum : int { KEY_U32 = 0, KEY_I32 = 1, KEY_F32 = 2 };
@@ -278,6 +291,16 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                                                                          uint32_t n, uint32_t seg_len0, uint32_t p0,
                                                                          uint32_t np) {
     __shared__ uint32_t s_h[4 * NCH * RADIX];
+#if GS_HIST_REPLICAS
+    // Pass-0 digit counts on 32 lane-private replicas, 16-bit counters packed two per dword: dword (d >> 1) * 32 +
+    // (lane & 31) lies in bank lane & 31, so a wave's add never meets a bank conflict — whatever the keys are: the
+    // 256-bin table of one position segment was the most expensive of the four (9.7 clk per wave-add against 7.5
+    // for the 4096-bin joint tables and 4.2 conflict-free, profiles/r02_lds_microbench.txt: 64 random lanes on
+    // 256 bins collide on ADDRESSES, which serialises atomics), and a constant low byte — every lane on one
+    // counter, 128 clk — costs nothing here.  Folded into s_h when the workgroup's segment changes, every
+    // HIST_FOLD_CHUNKS chunks (a replica sees 128 keys per chunk: 16-bit counters hold 511 chunks), and at the end.
+    __shared__ uint32_t s_r[RADIX / 2 * 32];
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t* hist = slab + SLAB_HIST;
     // This kernel is also the sort's CLEAR (reference: ClearMemory, OneSweepDispatcher.cuh:301-309): it zeroes the
@@ -295,6 +318,24 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     }
     const uint32_t bins = np * NCH * RADIX;
     for (uint32_t i = tid; i < bins; i += GHIST_THREADS) s_h[i] = 0;
+#if GS_HIST_REPLICAS
+    for (uint32_t i = tid; i < RADIX / 2 * 32; i += GHIST_THREADS) s_r[i] = 0;
+    uint32_t cur_x0 = 0xffffffffu, since_fold = 0;  // uniform: segment the replicas are counting for, chunks since the last fold
+    auto fold = [&](uint32_t x) {
+        __syncthreads();
+        if (x != 0xffffffffu)
+            for (uint32_t i = tid; i < RADIX / 2 * 32; i += GHIST_THREADS) {
+                const uint32_t v = s_r[i];
+                if (v) {
+                    s_r[i] = 0;
+                    const uint32_t d = (i >> 5) << 1;
+                    if (v & 0xffffu) atomicAdd(&s_h[hist_index(0, d, x)], v & 0xffffu);
+                    if (v >> 16) atomicAdd(&s_h[hist_index(0, d + 1u, x)], v >> 16);
+                }
+            }
+        __syncthreads();
+    };
+#endif
     __syncthreads();
 
     const uint32_t shift0 = p0 * 8u;
@@ -308,23 +349,41 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
     // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
     constexpr uint32_t HIST_UNROLL = GS_HIST_UNROLL;
-    auto process = [&](const uint4 t, const uint32_t x0) {
+    auto process = [&](const uint4 t, const uint32_t x0, const bool probe) {
             if (GS_EXP & 4) {  // ablation: stream only, count nothing
                 asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
                 return;
             }
             const uint32_t b[4] = {to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)};
+#if GS_HIST_REPLICAS
+            if (x0 != cur_x0 || since_fold >= HIST_FOLD_CHUNKS) {  // uniform
+                fold(cur_x0);
+                cur_x0 = x0;
+                since_fold = 0;
+            }
+            ++since_fold;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t d = (b[j] >> shift0) & 255u;
+                atomicAdd(&s_r[(d >> 1) * 32u + (lane & 31u)], 1u << ((d & 1u) * 16u));
+            }
+#endif
+#pragma unroll
+            for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < 4; ++q) {
                 if (q < np) {
                     uint32_t bin[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], q, x0);
                     // Skew (Thearling-Smith presets, constant bytes): same-address LDS atomics serialise
                     // per lane.  Cheap probe on the first key: do >= 8 lanes share the first lane's bin?
-                    const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin[0]);
-                    const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
-                    if (pc >= GS_HIST_SKEW_LANES) {
+                    // (only the first chunk of a work item probes: on every chunk the probe cost the uniform case
+                    //  10 % of the kernel, profiles/r02_ab_hist_variants.txt; skew does not come and go chunk by chunk)
+                    uint32_t b0 = 0, pc = 0;
+                    if (probe || (skew_mode & (1u << q))) {
+                        b0 = __builtin_amdgcn_readfirstlane(bin[0]);
+                        pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
+                    }
+                    if (GS_HIST_PROBE && probe && pc >= GS_HIST_SKEW_LANES) {
                         skew_mode |= 1u << q;
                         if (pc >= 24 || sticky[q] == 0xffffffffu) sticky[q] = b0;  // (re)learn the dominant bin
                     }
@@ -351,9 +410,18 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                 }
             }
     };
-    const uint32_t nchunks = (n + HIST_CHUNK - 1) / HIST_CHUNK;
-    for (uint32_t c0 = blockIdx.x * HIST_UNROLL; c0 < nchunks; c0 += gridDim.x * HIST_UNROLL) {
-        if ((unsigned long long)(c0 + HIST_UNROLL) * HIST_CHUNK <= n) {
+    const uint32_t nchunks_all = (n + HIST_CHUNK - 1) / HIST_CHUNK;
+#if GS_HIST_REPLICAS
+    // every workgroup takes ONE contiguous range of chunks: it stays inside a position segment (the replicas
+    // count for one segment at a time) and streams 1/gridDim of the array
+    const uint32_t per_wg = (nchunks_all + gridDim.x - 1) / gridDim.x;
+    const uint32_t c_first = blockIdx.x * per_wg, c_step = HIST_UNROLL;
+    const uint32_t nchunks = c_first + per_wg < nchunks_all ? c_first + per_wg : nchunks_all;
+#else
+    const uint32_t c_first = blockIdx.x * HIST_UNROLL, c_step = gridDim.x * HIST_UNROLL, nchunks = nchunks_all;
+#endif
+    for (uint32_t c0 = c_first; c0 < nchunks; c0 += c_step) {
+        if (c0 + HIST_UNROLL <= nchunks && (unsigned long long)(c0 + HIST_UNROLL) * HIST_CHUNK <= n) {
             // common case: HIST_UNROLL full chunks — UNCONDITIONAL loads (conditional ones get an
             // s_waitcnt vmcnt(0) each from the compiler and end up one at a time in flight)
             uint4 t[HIST_UNROLL];
@@ -361,7 +429,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             for (uint32_t u = 0; u < HIST_UNROLL; ++u)
                 t[u] = reinterpret_cast<const uint4*>(keys + (size_t)(c0 + u) * HIST_CHUNK)[tid];
 #pragma unroll
-            for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(t[u], (c0 + u) * HIST_CHUNK / seg_len0);
+            for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
             continue;
         }
         uint4 t[HIST_UNROLL];
@@ -376,7 +444,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             if (c0 + u < nchunks) {
                 const uint32_t x0 = base / seg_len0;  // uniform: a whole chunk lies in one position segment
                 if (base + HIST_CHUNK <= n) {
-                    process(t[u], x0);
+                    process(t[u], x0, true);
                 } else {
                     for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
                         const uint32_t kb = to_bits<KT>(keys[i]);
@@ -386,7 +454,11 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             }
         }
     }
+#if GS_HIST_REPLICAS
+    fold(cur_x0);
+#else
     __syncthreads();
+#endif
     for (uint32_t i = tid; i < bins; i += GHIST_THREADS) {
         const uint32_t v = s_h[i];
         if (v) atomicAdd(&hist[i], v);
@@ -659,6 +731,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     // a chain is the start order, so every predecessor of a claimed tile is running.
     // Only when that chain is already fully claimed does thread 0 try the others. ----
     uint32_t chain = blockIdx.x & (NCH - 1);
+    // geometry of the fast-path chain: requested before the ticket is (scalar loads that depend on blockIdx only), so
+    // their round trip runs beside the ticket atomic's instead of after the barrier
+    const uint32_t seg_start_f = info[I_START + chain], seg_end_f = info[I_END + chain], row_f = info[I_ROW + chain];
     if (tid == 0) {
         s_misc[2] = 0u;  // set by the look-back if it has to give up
         s_misc[8] = 0u;  // row a stuck look-back asks the workgroup to recount (GS_FALLBACK)
@@ -693,7 +768,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     uint32_t tile = uni(s_misc[1]);
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
-    uint32_t seg_start = uni(info[I_START + chain]), seg_end = uni(info[I_END + chain]);
+    uint32_t seg_start = uni(seg_start_f), seg_end = uni(seg_end_f), row0 = uni(row_f);
     if (GS_UNLIKELY(tile >= chain_tiles(seg_start, seg_end, TILE))) {  // uniform
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
@@ -743,6 +818,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         if (tile == 0xffffffffu) return;  // every chain is fully claimed
         seg_start = uni(info[I_START + chain]);
         seg_end = uni(info[I_END + chain]);
+        row0 = uni(info[I_ROW + chain]);
     }
     const uint32_t tile_base = (seg_start & ~63u) + tile * TILE;
     const uint32_t lo = tile_base > seg_start ? tile_base : seg_start;  // valid keys: [lo, hi)
@@ -750,7 +826,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     const uint32_t count = hi - lo;
     const uint32_t head = lo - tile_base;  // masked keys in front (first tile of a chain only)
     const bool full = (count == TILE);
-    uint32_t* cdesc = desc + (size_t)uni(info[I_ROW + chain]) * RADIX;  // row 0 of this chain
+    uint32_t* cdesc = desc + (size_t)row0 * RADIX;  // row 0 of this chain
     // Heavy layout: the slices of the heavy value's run (chains < NCH) and the digits above it (chain 2*NCH)
     // start where the counts gathered by the PREVIOUS pass say — tile 0 of such a chain seeds its row 0 now,
     // long before a successor can walk that far: seed of the heavy group's chain (set by scan_kernel)
@@ -1004,7 +1080,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         tile_total = run - dummies;
         if (!GS_FAULT_TILE(chain, tile))
             st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], (tile_total << 2) | FLAG_REDUCTION);
-        scan_incl = wave_inclusive_scan(run, lane);
+        scan_incl = wave_inclusive_scan_dpp(run);
         if (lane == 63) s_misc[4 + wave] = scan_incl;
     }
     __syncthreads();
@@ -1129,7 +1205,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             else if (nb == 4u) walk(IntTag<4>{});
             else walk(IntTag<16>{});
 #else
-            walk(IntTag<1>{});
+            walk(IntTag<GS_WALK_ROWS>{});
 #endif
             if (done) {
                 finished = true;
@@ -1269,6 +1345,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 uint32_t o = s_gbase[(k >> shift) & 255u] + i;
                 if (reverse) o = n - 1u - o;
                 if (GS_EXP & 1) o = (tile_base + i) % n;
+                if (GS_EXP & 256) o = o % n;
                 if (full || (i >= head && i < head + count)) {
                     st_stream(keys_out + o, from_bits<KT>(k));
                     st_stream(vals_out + o, v);
@@ -1330,6 +1407,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
                 if (reverse) o = n - 1u - o;
                 if (GS_EXP & 1) o = (tile_base + i) % n;
+                if (GS_EXP & 256) o = o % n;
                 if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
             }
         }

@@ -105,10 +105,24 @@ class OneSweep:
         self._alt_keys = None
         self._alt_vals = None
 
+    @classmethod
+    def _borrow(cls, handle, max_keys: int, mode: int, value_bytes: int, key_type: int = KEY_UINT32) -> "OneSweep":
+        """A view of a gs_onesweep handle somebody else owns (the local engine inside a gs_mgpu context)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.max_keys, self.order, self.key_type, self.mode = int(max_keys), ORDER_ASCENDING, key_type, mode
+        self.value_bytes = value_bytes if mode == MODE_PAIRS else 0
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self._alt_keys = self._alt_vals = None
+        return self
+
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.gs_onesweep_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.gs_onesweep_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -39,7 +39,8 @@ typedef enum gs_status {
     GS_ERR_HIP = 3,      /* a HIP runtime call failed (gs_last_hip_error() has the code) */
     GS_ERR_TIMEOUT = 4,  /* a bounded look-back spin expired on the device */
     GS_ERR_MODE = 5,     /* pairs call on a keys-only handle / value width mismatch */
-    GS_ERR_NO_DEVICE = 6 /* no gfx950 device visible */
+    GS_ERR_NO_DEVICE = 6, /* no gfx950 device visible */
+    GS_ERR_COMM = 7       /* multi-GPU: RCCL could not be loaded or a collective failed (gs_last_rccl_error()) */
 } gs_status;
 
 /* GPUSortingD3D12/GPUSorting.h:40-45 */
@@ -204,6 +205,63 @@ gs_status gs_msd_splitters_n(const uint64_t* hist, uint32_t nbins, uint32_t worl
  * by its top two bytes (two gs_onesweep_digit_pass calls: pass 2, then pass 3) is contiguous in that prefix. */
 gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type key_type,
                                          uint32_t* h_hist4096, void* stream);
+
+/* ---- multi-GPU: one process per GPU, MSD bucket split + RCCL exchange + per-GPU OneSweep -------------------
+ * BASELINE.json configs[3].  No reference counterpart (the reference is single-GPU; SURVEY.md 5.8, 8b proposed
+ * gs_onesweep_sort_sharded(gs_mgpu*, ...)).  Every rank of the job owns one gs_mgpu context; all calls below that
+ * say "collective" must be made by every rank, in the same order.
+ *
+ * Bootstrap as with NCCL: one rank calls gs_mgpu_get_unique_id and hands the 128 bytes to every rank over whatever
+ * it has (MPI, torch.distributed, a file); then every rank calls gs_mgpu_create (collective: ncclCommInitRank).
+ * RCCL (librccl.so.1) is loaded on first use; libgpusort.so does not depend on it otherwise. */
+#define GS_MGPU_UNIQUE_ID_BYTES 128
+typedef struct gs_mgpu gs_mgpu;
+gs_status gs_mgpu_get_unique_id(uint8_t id[GS_MGPU_UNIQUE_ID_BYTES]);
+/* shard_keys: most keys a rank passes in; capacity (>= shard_keys): most keys a rank can receive (its bucket of the
+ * global result; 1.25 x shard_keys is plenty for uniform keys).  Allocates the local sorter's scan state and one
+ * scratch array per key/value array (max(shard_keys, capacity) elements).  value_bytes 0 / 4 / 8 as gs_onesweep_create. */
+gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
+                         uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes);
+gs_status gs_mgpu_destroy(gs_mgpu* ctx);
+/* The sorted array is the concatenation over ranks of what each rank gets back.  Collective.  d_keys[0..n) (and
+ * d_vals) is this rank's shard (n may be 0; unchanged on return); d_out_keys / d_out_vals are caller-owned buffers
+ * of `capacity` elements that receive this rank's contiguous range of the global result, *out_n its length.  Stable
+ * (received order = source rank, source position).  Asynchronous on `stream` except for ONE wait on a few dozen
+ * words (per-peer counts: RCCL's send/recv take them as host integers).  GS_ERR_SIZE on EVERY rank if a bucket does
+ * not fit `capacity` even at 12-bit-prefix granularity. */
+gs_status gs_onesweep_sort_sharded(gs_mgpu* ctx, const void* d_keys, const void* d_vals, uint32_t n, gs_key_type key_type,
+                                   void* d_out_keys, void* d_out_vals, uint32_t* out_n, void* stream);
+/* Phase times of the last gs_onesweep_sort_sharded on this rank (HIP events on its stream; synchronises):
+ * ms[0] split (histogram + all-gather + plan + the host wait + partition pass), ms[1] bucket exchange,
+ * ms[2] local sort, ms[3] total; bytes this rank sent to / received from OTHER ranks; whether the 12-bit split ran. */
+gs_status gs_mgpu_get_profile(gs_mgpu* ctx, float ms[4], uint64_t* bytes_sent, uint64_t* bytes_received, uint32_t* fine_split);
+/* The exchange plan of the last call: [0] keys received, [1] overflow, [2] largest bucket, [3] 0, then
+ * send_counts[world], recv_counts[world], first_bin[world + 1]; `words` >= 4 + 3 * world + 1. */
+gs_status gs_mgpu_last_plan(gs_mgpu* ctx, uint32_t* plan, uint32_t words);
+gs_onesweep* gs_mgpu_sorter(gs_mgpu* ctx);               /* the local engine (tuning switches, gs_onesweep_check) */
+gs_status gs_mgpu_set_force_exchange(gs_mgpu* ctx, int on); /* run split + exchange even with one rank (tests) */
+int gs_last_rccl_error(void);                             /* ncclResult_t of the last failing RCCL call on this thread */
+
+/* The transport the pipeline runs on: RCCL by default; tests run several ranks on ONE GPU over a host-staged one.
+ * Both functions take device pointers and either enqueue on `stream` or complete before returning; 0 = success.
+ * exchange: for every array a < n_arrays and every peer p, send_counts[p] elements of elem_bytes[a] bytes from
+ * d_send[a] + send_displs[p] go to peer p, which receives them at d_recv[a] + recv_displs[self]; counts and
+ * displacements are host arrays of `world` entries, shared by all arrays. */
+typedef struct gs_mgpu_transport {
+    void* user;
+    int (*all_gather_u32)(void* user, const void* d_send, void* d_recv, size_t count, void* stream);
+    int (*exchange)(void* user, uint32_t n_arrays, const void* const* d_send, void* const* d_recv, const uint32_t* elem_bytes,
+                    const uint32_t* send_counts, const uint32_t* send_displs, const uint32_t* recv_counts,
+                    const uint32_t* recv_displs, void* stream);
+} gs_mgpu_transport;
+gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* transport, uint32_t rank, uint32_t world,
+                                        uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes);
+/* The plan as a host function (same rule as the device kernel; CPU tests, other transports): table[src * nbins + b] =
+ * keys of rank src in MSD bin b. */
+gs_status gs_msd_plan(const uint32_t* table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity, uint32_t* plan);
+/* Test hook: the device plan kernel on a host table (nbins 256 or 4096); synchronous. */
+gs_status gs_debug_msd_plan_device(const uint32_t* h_table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity,
+                                   uint32_t* h_plan, void* stream);
 
 #ifdef __cplusplus
 }

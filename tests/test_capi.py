@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -88,3 +89,69 @@ def test_product_does_not_import_the_oracle():
         p = os.path.join(ROOT, "include", f)
         if os.path.isfile(p):
             assert "gso_" not in open(p).read()
+
+
+def _numpy_plan(table, rank, capacity):
+    """Independent restatement of the exchange plan: equal-count splitters at bin granularity
+    (first bin whose exclusive prefix reaches ceil(r * total / world)), then [source, destination] counts."""
+    world, nbins = table.shape
+    g = table.astype(np.uint64).sum(axis=0)
+    excl = np.concatenate([[0], np.cumsum(g)[:-1]]).astype(np.uint64)
+    total = int(g.sum())
+    first = [0]
+    for r in range(1, world):
+        target = (total * r + world - 1) // world
+        first.append(int(np.count_nonzero(excl < target)))
+    first.append(nbins)
+    csum = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(table.astype(np.int64), axis=1)], axis=1)
+    per = csum[:, first[1:]] - csum[:, first[:-1]]          # [source, destination]
+    return {"send": per[rank].tolist(), "recv": per[:, rank].tolist(), "n_recv": int(per[:, rank].sum()),
+            "max_bucket": int(per.sum(axis=0).max()), "overflow": bool(per.sum(axis=0).max() > capacity), "first_bin": first}
+
+
+def _tables(rng):
+    for world, nbins in ((1, 256), (2, 256), (3, 256), (8, 256), (8, 4096), (5, 4096), (256, 256)):
+        t = rng.integers(0, 5000, size=(world, nbins), dtype=np.uint32)
+        yield t
+        t2 = t.copy()
+        t2[:, rng.integers(0, nbins)] += 3_000_000          # one heavy bin
+        yield t2
+        t3 = np.zeros_like(t)
+        t3[0, nbins - 1] = 7                                 # almost empty
+        yield t3
+        yield np.zeros_like(t)                               # empty
+
+
+def test_msd_plan_host_function():
+    """gs_msd_plan (host twin of the device plan kernel of the multi-GPU split) against a numpy restatement."""
+    from gpusorting_amd.sharded import msd_plan
+    rng = np.random.default_rng(5)
+    for t in _tables(rng):
+        world = t.shape[0]
+        for rank in sorted({0, world - 1, world // 2}):
+            cap = int(t.sum() // world * 1.2) + 1
+            got, ref = msd_plan(t, rank, cap), _numpy_plan(t, rank, cap)
+            assert got["send"] == ref["send"] and got["recv"] == ref["recv"], (t.shape, rank)
+            assert got["n_recv"] == ref["n_recv"] and got["max_bucket"] == ref["max_bucket"] and got["overflow"] == ref["overflow"]
+            assert got["first_bin"].tolist() == ref["first_bin"]
+
+
+@pytest.mark.gpu
+def test_msd_plan_device_kernel_equals_host(gpu):
+    """The device plan kernel (splitters + counts + overflow from the gathered histograms, no host round trip
+    besides the final counts) gives the host function's plan word for word."""
+    import ctypes as C
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    for t in _tables(rng):
+        world, nbins = t.shape
+        t = np.ascontiguousarray(t)
+        for rank in sorted({0, world - 1, world // 2}):
+            cap = int(t.sum() // world * 1.2) + 1
+            words = 4 + 3 * world + 1
+            host, dev = np.zeros(words, np.uint32), np.zeros(words, np.uint32)
+            p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+            assert lib.gs_msd_plan(p(t), nbins, world, rank, cap, p(host)) == 0
+            assert lib.gs_debug_msd_plan_device(p(t), nbins, world, rank, cap, p(dev), None) == 0
+            np.testing.assert_array_equal(dev, host, err_msg=f"world={world} nbins={nbins} rank={rank}")
