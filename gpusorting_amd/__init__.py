@@ -9,7 +9,7 @@ Only the hot path of b0nes164/GPUSorting named by BASELINE.json is here:
 """
 from .onesweep import (  # noqa: F401
     ENTROPY_PRESET_1, ENTROPY_PRESET_2, ENTROPY_PRESET_3, ENTROPY_PRESET_4, ENTROPY_PRESET_5,
-    KEY_FLOAT32, KEY_INT32, KEY_UINT32, MODE_KEYS_ONLY, MODE_PAIRS, ORDER_ASCENDING, ORDER_DESCENDING,
+    KEY_FLOAT32, KEY_FLOAT64, KEY_INT32, KEY_INT64, KEY_UINT32, KEY_UINT64, MODE_KEYS_ONLY, MODE_PAIRS, ORDER_ASCENDING, ORDER_DESCENDING,
     GPUSortingConfig, OneSweep, OneSweepDispatcher, init_random, validate,
 )
 from ._lib import GpuSortError  # noqa: F401

@@ -50,7 +50,7 @@ void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* 
 
 struct Shape {
     int threads, kpt;
-    BinLauncher fn[2][3][3];  // [rank mode][vb index 0/4/8][key type]; nullptr = not compiled
+    BinLauncher fn[2][3][6];  // [rank mode][vb index 0/4/8][key type: 3 x 32-bit, 3 x 64-bit]; nullptr = not compiled
 };
 
 #define GS_ROWS(T, K, R)                                                                             \
@@ -64,6 +64,17 @@ struct Shape {
         {launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {launch_bin<T, K, 4, 0, R>, nullptr, nullptr}, \
             {launch_bin<T, K, 8, 0, R>, nullptr, nullptr},                                           \
     }
+// every key type, 64-bit keys included (8-byte stage slots: tiles up to 8192 keys)
+#define GS_ROWS64(T, K, R)                                                                                                   \
+    {                                                                                                                        \
+        {launch_bin<T, K, 0, 0, R>, launch_bin<T, K, 0, 1, R>, launch_bin<T, K, 0, 2, R>, launch_bin<T, K, 0, 3, R>,         \
+         launch_bin<T, K, 0, 4, R>, launch_bin<T, K, 0, 5, R>},                                                              \
+            {launch_bin<T, K, 4, 0, R>, launch_bin<T, K, 4, 1, R>, launch_bin<T, K, 4, 2, R>, launch_bin<T, K, 4, 3, R>,     \
+             launch_bin<T, K, 4, 4, R>, launch_bin<T, K, 4, 5, R>},                                                          \
+            {launch_bin<T, K, 8, 0, R>, launch_bin<T, K, 8, 1, R>, launch_bin<T, K, 8, 2, R>, launch_bin<T, K, 8, 3, R>,     \
+             launch_bin<T, K, 8, 4, R>, launch_bin<T, K, 8, 5, R>},                                                          \
+    }
+#define GS_FULL64(T, K) {T, K, {GS_ROWS64(T, K, 0), GS_ROWS64(T, K, 1)}}
 #define GS_ROWS_KEYS(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}
 #define GS_KEYSONLY(T, K) {T, K, {GS_ROWS_KEYS(T, K, 0), GS_ROWS_KEYS(T, K, 1)}}
 #define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}}
@@ -72,7 +83,8 @@ struct Shape {
 const Shape g_shapes[] = {
     GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
     GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
-    GS_FULL(512, 16),   // mid sizes (n <= mid_keys): 8192-key tiles, shorter per-tile latency, more workgroups
+    GS_FULL64(512, 16), // mid sizes (n <= mid_keys): 8192-key tiles, shorter per-tile latency, more workgroups;
+                        // and the shape of 64-bit keys at every size (8-byte stage slots: 64 KiB per tile)
 #ifndef GS_NO_TUNING_SHAPES
     GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
     GS_U32ONLY(512, 20),  // 10 240-key tiles: 52 KiB of LDS, three workgroups per CU
@@ -131,14 +143,15 @@ size_t slab_words_for(uint32_t max_keys) {
     return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
 }
 
-using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t);
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 template <int KT>
 void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n,
-                 uint32_t seg_len0, uint32_t p0, uint32_t np) {
+                 uint32_t seg_len0, uint32_t p0, uint32_t np, uint32_t word) {
     hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, slab,
-                       used_words, n, seg_len0, p0, np);
+                       used_words, n, seg_len0, p0, np, word);
 }
-const HistLauncher g_hist[3] = {launch_hist<0>, launch_hist<1>, launch_hist<2>};
+const HistLauncher g_hist[6] = {launch_hist<0>, launch_hist<1>, launch_hist<2>, launch_hist<3>, launch_hist<4>, launch_hist<5>};
+inline bool is_key64(gs_key_type kt) { return (int)kt >= 3; }
 
 uint32_t hist_blocks(uint32_t n) {
     // one chunk per workgroup at mid sizes (measured: 4/8/16 chunks per workgroup — fewer closing global atomics,
@@ -156,7 +169,7 @@ struct PassPlan {
     uint32_t grid, desc_stride;
 };
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
-                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1) {
+                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
@@ -174,7 +187,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
-    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np);
+    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
@@ -191,7 +204,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
 
 gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n, gs_key_type kt, gs_order order) {
     if (!h || !a || !b || misaligned(a) || misaligned(b)) return GS_ERR_ARG;
-    if ((int)kt < 0 || (int)kt > 2 || (int)order < 0 || (int)order > 1) return GS_ERR_ARG;
+    if ((int)kt < 0 || (int)kt > 5 || (int)order < 0 || (int)order > 1) return GS_ERR_ARG;
     if (n == 0 || n > h->max_keys || n > GS_MAX_KEYS) return GS_ERR_SIZE;
     return GS_OK;
 }
@@ -203,12 +216,15 @@ template <int T, int K, int VB, int KT, int RANK>
 void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_t descending) {
     hipLaunchKernelGGL((gs::small_sort_kernel<T, K, VB, KT, RANK>), dim3(1), dim3(T), 0, s, keys, vals, n, descending);
 }
-#define GS_SMALL_ROW(T, K, VB, R) {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>}
-#define GS_SMALL_NONE {nullptr, nullptr, nullptr}
-// [size class][rank mode][vb index][key type]
-const SmallLauncher g_small[3][2][3][3] = {
-    {{GS_SMALL_ROW(512, 16, 0, 0), GS_SMALL_ROW(512, 16, 4, 0), GS_SMALL_ROW(512, 16, 8, 0)},
-     {GS_SMALL_ROW(512, 16, 0, 1), GS_SMALL_ROW(512, 16, 4, 1), GS_SMALL_ROW(512, 16, 8, 1)}},
+#define GS_SMALL_ROW(T, K, VB, R) {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>, nullptr, nullptr, nullptr}
+#define GS_SMALL_ROW64(T, K, VB, R)                                                                                   \
+    {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>, launch_small<T, K, VB, 3, R>, \
+     launch_small<T, K, VB, 4, R>, launch_small<T, K, VB, 5, R>}
+#define GS_SMALL_NONE {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+// [size class][rank mode][vb index][key type]; 64-bit keys: the 8192-slot class only
+const SmallLauncher g_small[3][2][3][6] = {
+    {{GS_SMALL_ROW64(512, 16, 0, 0), GS_SMALL_ROW64(512, 16, 4, 0), GS_SMALL_ROW64(512, 16, 8, 0)},
+     {GS_SMALL_ROW64(512, 16, 0, 1), GS_SMALL_ROW64(512, 16, 4, 1), GS_SMALL_ROW64(512, 16, 8, 1)}},
     {{GS_SMALL_ROW(1024, 16, 0, 0), GS_SMALL_ROW(1024, 16, 4, 0), GS_SMALL_NONE},
      {GS_SMALL_ROW(1024, 16, 0, 1), GS_SMALL_ROW(1024, 16, 4, 1), GS_SMALL_NONE}},
     {{GS_SMALL_ROW(1024, 32, 0, 0), GS_SMALL_NONE, GS_SMALL_NONE},
@@ -216,7 +232,7 @@ const SmallLauncher g_small[3][2][3][3] = {
 };
 inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_key_type kt) {
     const int cls = n <= 8192 ? 0 : n <= 16384 ? 1 : n <= 32768 ? 2 : 3;
-    return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;
+    return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
 }
 
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
@@ -233,32 +249,41 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         // the single-tile kernel has no spin and cannot time out
         return GS_OK;
     }
-    const int shape = (h->shape_auto && n <= mid_keys(vb)) ? MID_SHAPE : h->shape;
+    // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
+    int shape = (h->shape_auto && n <= mid_keys(vb)) ? MID_SHAPE : h->shape;
+    if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
     const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
-    PassPlan plan;
     // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
     // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
-    const uint32_t desc_bit = order == GS_ORDER_DESCENDING ? 1u : 0u;
     const uint32_t dyn = h->skip_passes ? 2u : 0u;
     // bit 2: the heavy-value layout may be used (its counts are gathered in the LDS-atomic ranking path only)
     // (measured: it pays for keys-only sorts; with values the counting costs more than the balanced chains
     // gain, profiles/r01_entropy_*); GPUSORT_HEAVY=0 switches it off
     // compiled into the keys-only kernels only; pays from 2^26 keys up (2^23..2^25: -3..-6 %, profiles/r01_heavy_threshold.txt)
-    const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && h->heavy != 0 && n >= h->heavy_min_keys;
-    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u), shape);
-    if (st != GS_OK) return st;
+    const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && !is_key64(kt) && h->heavy != 0 && n >= h->heavy_min_keys;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
-    for (uint32_t p = 0; p < 4; ++p) {
-        const uint32_t a = dyn ? 0u : (p & 1u);
-        const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
-        fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-           h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-           h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
-        if (h->profiling) GS_HIP(hipEventRecord(h->ev[4 + p], s));
+    // 64-bit keys: two rounds of histogram + scan + 4 passes — the low word's bytes, then (stable) the high word's.
+    // Each round leaves its result in the caller's buffers (an even number of passes runs, or identity passes are
+    // dropped in pairs), and only the last round carries the descending reversal.
+    const uint32_t rounds = is_key64(kt) ? 2u : 1u;
+    for (uint32_t word = 0; word < rounds; ++word) {
+        const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
+        PassPlan plan;
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u), shape, word);
+        if (st != GS_OK) return st;
+        for (uint32_t p = 0; p < 4; ++p) {
+            const uint32_t a = dyn ? 0u : (p & 1u);
+            const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
+            fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+               h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
+               h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8, mode);
+            if (h->profiling && word == 0) GS_HIP(hipEventRecord(h->ev[4 + p], s));
+        }
     }
+    if (h->profiling && rounds == 2) GS_HIP(hipEventRecord(h->ev[7], s));  // slot 6 then holds pass 3 of round 0 + all of round 1
     GS_HIP(hipGetLastError());
     h->hist_dirty = false;  // pass 0 (mode bit 2) was launched: it zeroes HIST
     h->profile_pending = h->profiling != 0;
@@ -543,19 +568,21 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
                                  void* stream) {
     gs_status st = check_common(h, d_keys_in, d_keys_out, n, kt, GS_ORDER_ASCENDING);
     if (st != GS_OK) return st;
-    if (pass > 3) return GS_ERR_ARG;
+    if (pass > (is_key64(kt) ? 7u : 3u)) return GS_ERR_ARG;
     uint32_t vb = 0;
     if (d_vals_in || d_vals_out) {
         if (h->mode != GS_MODE_PAIRS) return GS_ERR_MODE;
         if (!d_vals_in || !d_vals_out || misaligned(d_vals_in) || misaligned(d_vals_out)) return GS_ERR_ARG;
         vb = h->value_bytes;
     }
-    const Shape& sh = g_shapes[h->shape];
+    int shape = h->shape;
+    if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
+    const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     PassPlan plan;
-    st = prologue(h, d_keys_in, n, kt, s, pass, 1, &plan);  // a stand-alone pass: position segments on ANY input
+    st = prologue(h, d_keys_in, n, kt, s, pass & 3u, 1, &plan, 0, shape, pass >> 2);  // a stand-alone pass: position segments on ANY input
     if (st != GS_OK) return st;
     fn(s, plan.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,

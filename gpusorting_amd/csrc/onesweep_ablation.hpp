@@ -1,0 +1,55 @@
+// onesweep_ablation.hpp — ablation, tracing and fault-injection hooks of the OneSweep kernels.  NOT part of the
+// product build: onesweep_kernels.hpp includes this file only when GS_EXP != 0 (tools/README.md "experiment
+// builds", tests/test_gpu_fault.py).  GS_EXP flags:
+//   1   no look-back wait, sequential output positions (memory floor of the tile machinery)
+//   2   per-tile phase timestamps (10 ns ticks, lane 0 of wave 0) into the buffer whose address the host stored in
+//       the slab at STATUS+8; 8 words per (pass, block) — tools/trace_tiles.py
+//   4   histogram kernel streams the keys and counts nothing
+//   8   fault injection (cf. the reference's EmulatedDeadlocking.cu:36-37,339-345): tile 5 of chain 3 never publishes
+//       its descriptor, as if its workgroup had stalled.  With the fallback (default) its successors recount it and
+//       the sort is exact; with -DGS_FALLBACK=0 every later tile of that chain runs into the bounded spin, the sort
+//       still finishes, and gs_onesweep_check says GS_ERR_TIMEOUT.
+//   16 / 32  heavy-value counting / flush off;  64  heavy layout not used (counting still runs)
+//   256 no look-back wait with the real scatter shape: every earlier tile of the chain is assumed to hold this
+//       tile's digit counts (positions approximate, wrapped into range)
+#pragma once
+
+#define GS_FAULT_TILE(chain, tile) (((GS_EXP)&8) && (chain) == 3u && (tile) == 5u)
+
+#if (GS_EXP & 2)
+#define GS_TRACE_SETUP()                                                                                                  \
+    uint32_t* trace = reinterpret_cast<uint32_t*>(((unsigned long long)status[9] << 32) | status[8]) +                    \
+                      ((size_t)(shift >> 3) * gridDim.x + blockIdx.x) * 8;                                                \
+    uint32_t trace_trips = 0
+#define GS_TRACE(slot) do { if (tid == 0) trace[(slot)] = (uint32_t)wall_clock64(); } while (0)
+#define GS_TRACE_TRIP() ++trace_trips
+#define GS_TRACE_END(chain) do { if (tid == 0) trace[7] = trace_trips | ((chain) << 16) | (1u << 31); } while (0)
+#else
+#define GS_TRACE_SETUP() do { } while (0)
+#define GS_TRACE(slot) do { } while (0)
+#define GS_TRACE_TRIP() do { } while (0)
+#define GS_TRACE_END(chain) do { } while (0)
+#endif
+
+#if (GS_EXP & 4)
+#define GS_ABL_HIST_STREAM_ONLY(t) do { asm volatile("" ::"v"((t).x), "v"((t).y), "v"((t).z), "v"((t).w)); return; } while (0)
+#else
+#define GS_ABL_HIST_STREAM_ONLY(t) do { } while (0)
+#endif
+
+#define GS_ABL_NO_HEAVY_COUNT (((GS_EXP)&16) != 0)
+#define GS_ABL_NO_HEAVY_FLUSH (((GS_EXP)&32) != 0)
+#define GS_ABL_NO_HEAVY_LAYOUT (((GS_EXP)&64) != 0)
+#define GS_ABL_LOOKBACK_SKIPPED (((GS_EXP)&1) != 0)
+#define GS_ABL_GENERIC_SCATTER (((GS_EXP)&257) != 0)
+#if (GS_EXP & 256)
+#define GS_ABL_ASSUME_PREV() do { if (!finished) { prev = (ld_agent(&cdesc[tid]) >> 2) + tile * tile_total; done = true; } } while (0)
+#else
+#define GS_ABL_ASSUME_PREV() do { } while (0)
+#endif
+// positions are meaningless without the look-back: sequential (1) or wrapped into the array (256)
+#define GS_ABL_OUT_INDEX(o, i)                                     \
+    do {                                                           \
+        if ((GS_EXP)&1) (o) = (tile_base + (i)) % n;               \
+        if ((GS_EXP)&256) (o) = (o) % n;                           \
+    } while (0)

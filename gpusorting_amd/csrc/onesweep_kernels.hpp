@@ -51,11 +51,6 @@ constexpr uint32_t STATUS_TIMEOUT = 4;  // == GS_ERR_TIMEOUT
 #define GS_SPIN_LIMIT (1u << 21)
 #endif
 constexpr uint32_t SPIN_LIMIT = GS_SPIN_LIMIT;
-// GS_EXP & 8 (fault-injection builds, cf. the reference's EmulatedDeadlocking.cu:36-37,339-345): tile 5 of
-// chain 3 never publishes its descriptor, as if its workgroup had stalled.  With the fallback (default) its
-// successors recount it and the sort is exact; with -DGS_FALLBACK=0 every later tile of that chain runs into the
-// bounded spin, the sort still finishes, and gs_onesweep_check says GS_ERR_TIMEOUT.
-#define GS_FAULT_TILE(chain, tile) (((GS_EXP)&8) && (chain) == 3u && (tile) == 5u)
 
 #ifndef GS_NCHAINS
 #define GS_NCHAINS 16  // independent chained scans per pass (power of two, <= 32)
@@ -63,17 +58,28 @@ constexpr uint32_t SPIN_LIMIT = GS_SPIN_LIMIT;
 constexpr uint32_t NCH = GS_NCHAINS;
 static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must be a power of two <= 32");
 
+// Ablation / instrumented / fault-injection builds (-DGS_EXP=<flags>, tools/ and tests/test_gpu_fault.py) hook into
+// the kernels through the GS_ABL_* / GS_TRACE* macros below; their code lives in onesweep_ablation.hpp and is not
+// part of the product translation unit (GS_EXP == 0: every hook is empty or a compile-time false).
 #ifndef GS_EXP
-#define GS_EXP 0  // experiment flags (ablation / instrumented builds only): 1 no look-back wait (sequential output),
-                  // 2 per-tile phase trace, 4 histogram streams only, 8 fault injection, 16/32 heavy-value counting /
-                  // flush off, 64 heavy layout not used (counting still runs), 256 no wait with the real scatter shape
+#define GS_EXP 0
 #endif
-// GS_EXP & 2: per-tile phase timestamps (10 ns ticks, lane 0 of wave 0) into the buffer whose
-// address the host stored in the slab at STATUS+8; 8 words per (pass, block).
-#if (GS_EXP & 2)
-#define GS_TRACE(slot) do { if (tid == 0) trace[(slot)] = (uint32_t)wall_clock64(); } while (0)
+#if GS_EXP
+#include "onesweep_ablation.hpp"
 #else
+#define GS_FAULT_TILE(chain, tile) false       // fault injection: this tile never publishes its descriptor
+#define GS_TRACE_SETUP() do { } while (0)      // per-tile phase timestamps
 #define GS_TRACE(slot) do { } while (0)
+#define GS_TRACE_TRIP() do { } while (0)
+#define GS_TRACE_END(chain) do { } while (0)
+#define GS_ABL_HIST_STREAM_ONLY(t) do { } while (0)   // histogram kernel: stream the keys, count nothing
+#define GS_ABL_NO_HEAVY_LAYOUT false           // heavy-value chains not used although counted
+#define GS_ABL_NO_HEAVY_COUNT false            // heavy-value counting off
+#define GS_ABL_NO_HEAVY_FLUSH false            // heavy-value counts not handed to the next pass
+#define GS_ABL_LOOKBACK_SKIPPED false          // no look-back wait
+#define GS_ABL_ASSUME_PREV() do { } while (0)  // no wait, positions extrapolated from this tile's own counts
+#define GS_ABL_GENERIC_SCATTER false           // force the generic (masked) scatter loops
+#define GS_ABL_OUT_INDEX(o, i) do { } while (0)  // rewrite an output index (sequential / wrapped)
 #endif
 // (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
 //  returns a not-yet-final row and the wait moves in front of staging)
@@ -185,7 +191,12 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_DESC % 4 == 0, "r
 constexpr uint32_t HIST_FOLD_CHUNKS = 256;  // replicas are folded at least this often (16-bit counters, 128 keys per replica per chunk)
 constexpr uint32_t HIST_CHUNK = 4 * GS_GHIST_THREADS;  // keys per histogram work item (4 per thread); position segments are multiples of it
 
-enum : int { KEY_U32 = 0, KEY_I32 = 1, KEY_F32 = 2 };
+enum : int { KEY_U32 = 0, KEY_I32 = 1, KEY_F32 = 2, KEY_U64 = 3, KEY_I64 = 4, KEY_F64 = 5 };
+// 64-bit keys (8 passes; the reference has 32-bit keys only) are sorted as two 4-pass rounds over
+// the SAME machinery: round 0 partitions by the bytes of the low word, round 1 (stable) by the bytes of the high
+// word; both words travel as one 8-byte element.  KW = 32-bit words per key.
+template <int KT>
+struct KeyWords { static constexpr int value = KT >= KEY_U64 ? 2 : 1; };
 
 template <int KT>
 __device__ __forceinline__ uint32_t to_bits(uint32_t u) {
@@ -224,6 +235,39 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 #else
     *p = v;
 #endif
+}
+
+// 64-bit keys: native (lo, hi) words -> radix-sortable words and back (the 32-bit rules of SortCommon.hlsl:134-154
+// applied to the 64-bit pattern: signed flips the sign bit, floating point flips all bits of negatives too)
+template <int KT>
+__device__ __forceinline__ uint2 to_bits2(uint2 k) {
+    if constexpr (KT == KEY_I64) k.y ^= 0x80000000u;
+    if constexpr (KT == KEY_F64) {
+        const uint32_t m = (uint32_t)(-(int32_t)(k.y >> 31));
+        k.x ^= m;
+        k.y ^= m | 0x80000000u;
+    }
+    return k;
+}
+template <int KT>
+__device__ __forceinline__ uint2 from_bits2(uint2 k) {
+    if constexpr (KT == KEY_I64) k.y ^= 0x80000000u;
+    if constexpr (KT == KEY_F64) {
+        const uint32_t m = (k.y >> 31) - 1u;
+        k.x ^= m;
+        k.y ^= m | 0x80000000u;
+    }
+    return k;
+}
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ uint2 ld_stream(const uint2* p) {
+    const u32x2_t v = ld_stream<NT>(reinterpret_cast<const u32x2_t*>(p));
+    return uint2{v.x, v.y};
+}
+__device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
+    st_stream(reinterpret_cast<u32x2_t*>(p), u32x2_t{v.x, v.y});
 }
 
 template <int N>
@@ -285,11 +329,14 @@ __host__ __device__ constexpr uint32_t hist_index(uint32_t q, uint32_t d, uint32
     return q == 0 ? x * RADIX + d : (q * RADIX + d) * NCH + x;
 }
 
+// 64-bit keys: `word` selects the 32-bit word the np digits are taken from (the sort's round); a work item is still
+// HIST_CHUNK keys — two 16-byte loads per thread instead of one.
 template <int KT>
 __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                          uint32_t* slab, size_t slab_used_words,
                                                                          uint32_t n, uint32_t seg_len0, uint32_t p0,
-                                                                         uint32_t np) {
+                                                                         uint32_t np, uint32_t word) {
+    constexpr int KW = KeyWords<KT>::value;
     __shared__ uint32_t s_h[4 * NCH * RADIX];
 #if GS_HIST_REPLICAS
     // Pass-0 digit counts on 32 lane-private replicas, 16-bit counters packed two per dword: dword (d >> 1) * 32 +
@@ -349,12 +396,9 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
     // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
     constexpr uint32_t HIST_UNROLL = GS_HIST_UNROLL;
-    auto process = [&](const uint4 t, const uint32_t x0, const bool probe) {
-            if (GS_EXP & 4) {  // ablation: stream only, count nothing
-                asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
-                return;
-            }
-            const uint32_t b[4] = {to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)};
+    auto process = [&](const uint4 t, const uint32_t x0, const bool probe) {  // t: four keys' digit words, sortable form
+            GS_ABL_HIST_STREAM_ONLY(t);
+            const uint32_t b[4] = {t.x, t.y, t.z, t.w};
 #if GS_HIST_REPLICAS
             if (x0 != cur_x0 || since_fold >= HIST_FOLD_CHUNKS) {  // uniform
                 fold(cur_x0);
@@ -410,6 +454,21 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                 }
             }
     };
+    // the four keys of thread tid in chunk c, reduced to their digit words (radix-sortable form)
+    auto word_of = [&](uint32_t lo, uint32_t hi) {
+        const uint2 b = to_bits2<KT>(uint2{lo, hi});
+        return word ? b.y : b.x;
+    };
+    auto load_chunk = [&](uint32_t c) -> uint4 {
+        if constexpr (KW == 2) {
+            const uint4* p = reinterpret_cast<const uint4*>(keys) + (size_t)c * (HIST_CHUNK / 2);
+            const uint4 a = p[tid], b2 = p[tid + GHIST_THREADS];
+            return uint4{word_of(a.x, a.y), word_of(a.z, a.w), word_of(b2.x, b2.y), word_of(b2.z, b2.w)};
+        } else {
+            const uint4 a = reinterpret_cast<const uint4*>(keys + (size_t)c * HIST_CHUNK)[tid];
+            return uint4{to_bits<KT>(a.x), to_bits<KT>(a.y), to_bits<KT>(a.z), to_bits<KT>(a.w)};
+        }
+    };
     const uint32_t nchunks_all = (n + HIST_CHUNK - 1) / HIST_CHUNK;
 #if GS_HIST_REPLICAS
     // every workgroup takes ONE contiguous range of chunks: it stays inside a position segment (the replicas
@@ -426,8 +485,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             // s_waitcnt vmcnt(0) each from the compiler and end up one at a time in flight)
             uint4 t[HIST_UNROLL];
 #pragma unroll
-            for (uint32_t u = 0; u < HIST_UNROLL; ++u)
-                t[u] = reinterpret_cast<const uint4*>(keys + (size_t)(c0 + u) * HIST_CHUNK)[tid];
+            for (uint32_t u = 0; u < HIST_UNROLL; ++u) t[u] = load_chunk(c0 + u);
 #pragma unroll
             for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
             continue;
@@ -436,7 +494,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
             const uint32_t base = (c0 + u) * HIST_CHUNK;
-            if (c0 + u < nchunks && base + HIST_CHUNK <= n) t[u] = reinterpret_cast<const uint4*>(keys + base)[tid];
+            if (c0 + u < nchunks && base + HIST_CHUNK <= n) t[u] = load_chunk(c0 + u);
         }
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
@@ -447,7 +505,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                     process(t[u], x0, true);
                 } else {
                     for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
-                        const uint32_t kb = to_bits<KT>(keys[i]);
+                        const uint32_t kb = KW == 2 ? word_of(keys[2 * (size_t)i], keys[2 * (size_t)i + 1]) : to_bits<KT>(keys[i]);
                         for (uint32_t q = 0; q < np; ++q) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
                     }
                 }
@@ -547,7 +605,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     uint32_t h_use = 0xffffffffu, h_cnt = 0xffffffffu;  // uniform
     if (heavy_on) {
         // the slices of pass q are counted by pass q-1 while it writes them: both passes must run
-        if (!(GS_EXP & 64) && q >= 1 && s_best[0] != 0 && ((skip >> (q - 1)) & 3u) == 0u) h_use = 255u - (uint32_t)(s_best[0] & 255u);
+        if (!GS_ABL_NO_HEAVY_LAYOUT && q >= 1 && s_best[0] != 0 && ((skip >> (q - 1)) & 3u) == 0u) h_use = 255u - (uint32_t)(s_best[0] & 255u);
         if (q < 3 && s_best[1] != 0 && ((skip >> q) & 3u) == 0u) h_cnt = 255u - (uint32_t)(s_best[1] & 255u);
     }
     if (tid == h_use) { s_hv[0][0] = base_prev + incl_prev - gprev; s_hv[0][1] = gprev; }
@@ -654,7 +712,7 @@ struct ValT { using type = uint32_t; };
 template <>
 struct ValT<8> { using type = uint64_t; };
 
-template <int THREADS, int KPT, int VB>
+template <int THREADS, int KPT, int VB, int KW = 1>
 struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
@@ -662,10 +720,10 @@ struct BinCfg {
     // the same loop — no second staging round, no saved positions/digits, two barriers fewer per tile
     // (8-byte values the same way need a 512 x 24 tile, 12 288 pairs x 12 B = 144 KiB in two LDS arrays: measured
     //  5.975 vs 6.014 ms, not worth a shape of its own; the code path stays generic in VB)
-    static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4;
-    static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : TILE * (VB == 8 ? 8 : 4);
+    static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4 && KW == 1;
+    static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : TILE * ((VB == 8 || KW == 2) ? 8 : 4);
     // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
-    static constexpr bool HEAVY = GS_HEAVY && VB == 0;
+    static constexpr bool HEAVY = GS_HEAVY && VB == 0 && KW == 1;
     static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
@@ -676,27 +734,32 @@ struct BinCfg {
     static constexpr int BPC = BPC_RAW < 1 ? 1 : BPC_RAW;
     static constexpr int WAVES_PER_SIMD_RAW = BPC * THREADS / 256;
     // never ask for fewer registers than the unrolled tile needs (~1.5 regs/key + temps)
-    static constexpr int VGPR_NEED = KPT * (VB == 8 ? 3 : 2) + 32;
+    static constexpr int VGPR_NEED = KPT * ((VB == 8 ? 3 : 2) + (KW == 2 ? 1 : 0)) + 32;
     static constexpr int WAVES_PER_SIMD_CAP = 512 / VGPR_NEED < 1 ? 1 : 512 / VGPR_NEED;
     static constexpr int WAVES_PER_SIMD =
         WAVES_PER_SIMD_RAW < WAVES_PER_SIMD_CAP ? WAVES_PER_SIMD_RAW : WAVES_PER_SIMD_CAP;
 };
 
 template <int THREADS, int KPT, int VB, int KT, int RANK>
-__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)) void digit_binning_kernel(
+__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value>::WAVES_PER_SIMD)) void digit_binning_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b,  // the pass reads a and writes b, unless ...
     uint32_t* desc,          // this pass: rows of 256 descriptor words; chain x starts at row_base[x]
     uint32_t* counters,      // this pass: one ticket counter per chain
     const uint32_t* info,    // this pass: the info block written by scan_kernel
     uint32_t* hsub,          // SLAB_HSUB: read [pass] (heavy layout), added to [pass + 1] (counting pass)
-    uint32_t* status, uint32_t n, uint32_t shift,
+    uint32_t* status, uint32_t n, uint32_t shift_full /*bit position of the digit in the key: 0..24, 64-bit keys 0..56*/,
     uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
                     on the last pass that runs (PF_LAST); bit2: zero the HIST region*/) {
-    using Cfg = BinCfg<THREADS, KPT, VB>;
+    constexpr int KW = KeyWords<KT>::value;
+    using Cfg = BinCfg<THREADS, KPT, VB, KW>;
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
     constexpr uint32_t TILE = Cfg::TILE;
+    // the digit's position inside the word that holds it; 64-bit keys: hi_word says which word that is.  key[] is
+    // always that word (radix-sortable form), key2[] the other one, which just travels along.
+    const uint32_t shift = shift_full & 31u;
+    const bool hi_word = KW == 2 && shift_full >= 32u;
     static_assert(THREADS >= 256 && THREADS % 64 == 0, "need >= 256 threads");
     static_assert(KPT % 4 == 0 && TILE <= 65536, "offsets are packed 2 x 16 bit, digits 4 x 8 bit");
 
@@ -720,11 +783,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     if constexpr (Cfg::HEAVY)
         for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
-#if (GS_EXP & 2)
-    uint32_t* trace = reinterpret_cast<uint32_t*>(((unsigned long long)status[9] << 32) | status[8]) +
-                      ((size_t)(shift >> 3) * gridDim.x + blockIdx.x) * 8;
-    uint32_t trace_trips = 0;
-#endif
+    GS_TRACE_SETUP();
     GS_TRACE(0);
     // ---- claim a tile.  Fast path: ONE returning atomic on the ticket counter of
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
@@ -842,10 +901,32 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
     }
     GS_TRACE(1);
 
-    // ---- load (wave-striped, coalesced 256 B per wave-instruction) ----
+    // ---- load (wave-striped, coalesced 256 B per wave-instruction; 64-bit keys: 512 B) ----
     uint32_t key[KPT];
+    uint32_t key2[KW == 2 ? KPT : 1];
     const uint32_t my_base = tile_base + wave * (64u * KPT) + lane;
-    if (GS_LIKELY(full)) {
+    if constexpr (KW == 2) {
+        const uint2* kin2 = reinterpret_cast<const uint2*>(keys_in);
+        uint2 raw[KPT];
+        if (GS_LIKELY(full)) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) raw[i] = ld_stream<VB == 0>(kin2 + my_base + i * 64u);
+        } else {  // unconditional loads on a clamped index, masked below (see the 32-bit form)
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = my_base + i * 64u;
+                raw[i] = ld_stream<VB == 0>(kin2 + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            const uint2 b = to_bits2<KT>(raw[i]);
+            key[i] = hi_word ? b.y : b.x;
+            key2[i] = hi_word ? b.x : b.y;
+            if (!full) key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : key[i]);
+        }
+    } else if (GS_LIKELY(full)) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(ld_stream<VB == 0>(keys_in + my_base + i * 64u));
     } else {
@@ -986,7 +1067,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             // keys.  A loop of its own — inside the ranking loop its non-returning adds made the compiler wait
             // for every ranking atomic (+0.17 ms per pass).  Every thread keeps the count of its own most
             // frequent next digit (the first it meets) in a register; only the other keys cost an LDS add.
-            if (cnt_h != 0xffffffffu && !(GS_EXP & 16)) {  // uniform
+            if (cnt_h != 0xffffffffu && !GS_ABL_NO_HEAVY_COUNT) {  // uniform
                 uint32_t cnt_mine = 0xffffffffu, cnt_l0 = 0;
                 const uint32_t grp_lo = cnt_h & ~(RADIX / NCH - 1u);
                 // straight-line selects and ONE predicated add per key (the branchy form cost 45 instructions
@@ -1116,7 +1197,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if constexpr (Cfg::FUSED) {
                 stage_pair(lpos, key[i], val[i]);
             } else {
-                s_stage[lpos] = key[i];
+                if constexpr (KW == 2) reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], key2[i]};  // (digit word, other word)
+                else s_stage[lpos] = key[i];
                 if constexpr (VB != 0) {  // values follow the same positions later
                     if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
                     else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
@@ -1131,7 +1213,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             if constexpr (Cfg::FUSED) {
                 if (my_base + i * 64u < hi) stage_pair(lpos, key[i], val[i]);
             } else {
-                if (my_base + i * 64u < hi) s_stage[lpos] = key[i];
+                if (my_base + i * 64u < hi) {
+                    if constexpr (KW == 2) reinterpret_cast<uint2*>(s_raw)[lpos] = uint2{key[i], key2[i]};
+                    else s_stage[lpos] = key[i];
+                }
                 if constexpr (VB != 0) {
                     if ((i & 1) == 0) offp[i >> 1] = (offp[i >> 1] & 0xffff0000u) | lpos;
                     else offp[i >> 1] = (offp[i >> 1] & 0x0000ffffu) | (lpos << 16);
@@ -1155,13 +1240,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
 #endif
     uint32_t prev = 0, spins = 0;
     int32_t k = (int32_t)tile;
-    bool done = (GS_EXP & 1) != 0, poisoned = false, finished = tid >= RADIX;
+    bool done = GS_ABL_LOOKBACK_SKIPPED, poisoned = false, finished = tid >= RADIX;
     auto walk = [&](auto nb_tag) {
         constexpr int NB = decltype(nb_tag)::value;
         while (!done) {
-#if (GS_EXP & 2)
-            ++trace_trips;
-#endif
+            GS_TRACE_TRIP();
             uint32_t v[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -1194,10 +1277,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
     };
     GS_TRACE(4);
-#if (GS_EXP & 256)  // ablation: no look-back wait, but the real scatter pattern — every earlier tile of the chain is
-                    // assumed to hold the same digit counts as this one (positions approximate, wrapped into range)
-    if (!finished) { prev = (ld_agent(&cdesc[tid]) >> 2) + tile * tile_total; done = true; }
-#endif
+    GS_ABL_ASSUME_PREV();
     for (;;) {
         if (!finished) {
 #if GS_ADAPTIVE_BATCH
@@ -1238,8 +1318,16 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
             // every thread has read the request (fb_row above) before it is withdrawn; the next request can only
             // be posted after the barrier that ends this block
             if (tid == 0) s_misc[8] = 0u;
-            for (uint32_t idx = flo + tid; idx < fhi; idx += THREADS)
-                atomicAdd(&s_fb[(to_bits<KT>(keys_in[idx]) >> shift) & 255u], 1u);
+            for (uint32_t idx = flo + tid; idx < fhi; idx += THREADS) {
+                uint32_t w;
+                if constexpr (KW == 2) {
+                    const uint2 b = to_bits2<KT>(reinterpret_cast<const uint2*>(keys_in)[idx]);
+                    w = hi_word ? b.y : b.x;
+                } else {
+                    w = to_bits<KT>(keys_in[idx]);
+                }
+                atomicAdd(&s_fb[(w >> shift) & 255u], 1u);
+            }
             __syncthreads();
             if (!finished) {
                 if (k == (int32_t)fb_row) {
@@ -1254,9 +1342,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
         }
     }
     GS_TRACE(5);
-#if (GS_EXP & 2)
-    if (tid == 0) trace[7] = trace_trips | (chain << 16) | (1u << 31);
-#endif
+    GS_TRACE_END(chain);
     if (uni(s_misc[2]) != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
@@ -1324,7 +1410,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 v = reinterpret_cast<const V*>(s_raw + TILE * 4)[slot];
             }
         };
-        if (GS_LIKELY(full) && !(GS_EXP & 257)) {
+        if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
             uint32_t kk[KPT];
             V vv[KPT];
 #pragma unroll
@@ -1344,37 +1430,55 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 load_pair(i, k, v);
                 uint32_t o = s_gbase[(k >> shift) & 255u] + i;
                 if (reverse) o = n - 1u - o;
-                if (GS_EXP & 1) o = (tile_base + i) % n;
-                if (GS_EXP & 256) o = o % n;
+                GS_ABL_OUT_INDEX(o, i);
                 if (full || (i >= head && i < head + count)) {
                     st_stream(keys_out + o, from_bits<KT>(k));
                     st_stream(vals_out + o, v);
                 }
             }
         }
-    } else if (GS_LIKELY(full) && !(GS_EXP & 257)) {
+    } else if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
         // the common case as straight-line code: all stage reads first, then the base look-ups, then the stores
         // (with the masks and the reversal in the loop every key got its own branches and LDS round trips)
-        uint32_t kb[KPT];
+        if constexpr (KW == 2) {
+            uint2 kb[KPT];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) kb[j] = s_stage[tid + j * THREADS];
+            for (int j = 0; j < KPT; ++j) kb[j] = reinterpret_cast<const uint2*>(s_raw)[tid + j * THREADS];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (kb[j] >> shift) & 255u;
-            st_stream(keys_out + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
-            if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t d = (kb[j].x >> shift) & 255u;
+                const uint2 nat = from_bits2<KT>(hi_word ? uint2{kb[j].y, kb[j].x} : kb[j]);
+                st_stream(reinterpret_cast<uint2*>(keys_out) + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), nat);
+                if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+            }
+        } else {
+            uint32_t kb[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) kb[j] = s_stage[tid + j * THREADS];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t d = (kb[j] >> shift) & 255u;
+                st_stream(keys_out + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
+                if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
+            }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t i = tid + j * THREADS;
-            const uint32_t kb = s_stage[i];
+            uint2 kb2 = {0u, 0u};
+            if constexpr (KW == 2) kb2 = reinterpret_cast<const uint2*>(s_raw)[i];
+            const uint32_t kb = KW == 2 ? kb2.x : s_stage[i];
             const uint32_t d = (kb >> shift) & 255u;
             uint32_t o = s_gbase[d] + i;
             if (reverse) o = n - 1u - o;
-            if (GS_EXP & 1) o = (tile_base + i) % n;  // ablation: positions are meaningless without the look-back
-            if (GS_EXP & 256) o = o % n;
-            if (full || (i >= head && i < head + count)) st_stream(keys_out + o, from_bits<KT>(kb));
+            GS_ABL_OUT_INDEX(o, i);
+            if (full || (i >= head && i < head + count)) {
+                if constexpr (KW == 2)
+                    st_stream(reinterpret_cast<uint2*>(keys_out) + o, from_bits2<KT>(hi_word ? uint2{kb2.y, kb2.x} : kb2));
+                else
+                    st_stream(keys_out + o, from_bits<KT>(kb));
+            }
             if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
         }
     }
@@ -1393,7 +1497,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 if (my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
         }
         __syncthreads();
-        if (GS_LIKELY(full) && !(GS_EXP & 257)) {
+        if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
             V vv[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) vv[j] = s_vstage[tid + j * THREADS];
@@ -1406,13 +1510,12 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB>::WAVES_PER_SIMD)
                 const uint32_t i = tid + j * THREADS;
                 uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
                 if (reverse) o = n - 1u - o;
-                if (GS_EXP & 1) o = (tile_base + i) % n;
-                if (GS_EXP & 256) o = o % n;
+                GS_ABL_OUT_INDEX(o, i);
                 if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
             }
         }
     }
-    if (GS_UNLIKELY(cnt_h != 0xffffffffu && !(GS_EXP & 32))) {  // hand the tile's counts to the next pass
+    if (GS_UNLIKELY(cnt_h != 0xffffffffu && !GS_ABL_NO_HEAVY_FLUSH)) {  // hand the tile's counts to the next pass
         uint32_t* hs = hsub + ((shift >> 3) + 1u) * HSUB_STRIDE;
         if (cnt_split) __syncthreads();  // the recount is complete
         for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) {
@@ -1489,10 +1592,12 @@ template <int SMALL_THREADS, int SMALL_KPT, int VB, int KT, int RANK>
 __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* keys, void* vals_, uint32_t n,
                                                                    uint32_t descending) {
     using V = typename ValT<VB>::type;
+    constexpr int KW = KeyWords<KT>::value;  // 64-bit keys: eight passes, both words staged
     constexpr int KPT = SMALL_KPT, WAVES = SMALL_THREADS / 64;
     constexpr uint32_t SMALL_TILE = SMALL_THREADS * SMALL_KPT;
-    static_assert(SMALL_TILE * (4 + (VB == 8 ? 8 : VB)) + WAVES * RADIX * 4 + 64 <= 160 * 1024, "LDS");
+    static_assert(SMALL_TILE * (4 * KW + (VB == 8 ? 8 : VB)) + WAVES * RADIX * 4 + 64 <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[SMALL_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage2[KW == 2 ? SMALL_TILE : 1];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? SMALL_TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];
     __shared__ uint32_t s_wtot[4];
@@ -1500,32 +1605,52 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
     const uint32_t my_base = wave * (64u * KPT) + lane;
     uint32_t* whist = s_whist + wave * RADIX;
 
-    uint32_t key[KPT];
+    uint32_t key[KPT];                      // low word (the only one for 32-bit keys)
+    uint32_t keyh[KW == 2 ? KPT : 1];       // high word
     V val[VB != 0 ? KPT : 1];
     // unconditional loads on a clamped index, masked afterwards (guarded loads are issued one at a time)
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t idx = my_base + i * 64u;
         const uint32_t ci = idx < n ? idx : n - 1u;
-        key[i] = keys[ci];
+        if constexpr (KW == 2) {
+            const uint2 k = reinterpret_cast<const uint2*>(keys)[ci];
+            key[i] = k.x;
+            keyh[i] = k.y;
+        } else {
+            key[i] = keys[ci];
+        }
         if constexpr (VB != 0) val[i] = reinterpret_cast<const V*>(vals_)[ci];
     }
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < n ? to_bits<KT>(key[i]) : 0xffffffffu;
+    for (int i = 0; i < KPT; ++i) {
+        const bool valid = my_base + i * 64u < n;
+        if constexpr (KW == 2) {
+            const uint2 b = to_bits2<KT>(uint2{key[i], keyh[i]});
+            key[i] = valid ? b.x : 0xffffffffu;
+            keyh[i] = valid ? b.y : 0xffffffffu;
+        } else {
+            key[i] = valid ? to_bits<KT>(key[i]) : 0xffffffffu;
+        }
+    }
 
 #pragma unroll 1
-    for (uint32_t shift = 0; shift < 32; shift += 8) {
+    for (uint32_t shift_full = 0; shift_full < 32u * KW; shift_full += 8) {
+        const uint32_t shift = shift_full & 31u;
+        const bool hi_word = KW == 2 && shift_full >= 32u;
+        auto dword = [&](int i) { return KW == 2 && hi_word ? keyh[KW == 2 ? i : 0] : key[i]; };  // the word holding this pass's digit
         for (uint32_t i = tid; i < WAVES * RADIX; i += SMALL_THREADS) s_whist[i] = 0;
         __syncthreads();
         uint32_t off[KPT];
         if constexpr (RANK == 0) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t w = dword(i);
+                const uint32_t d = (w >> shift) & 255u;
                 uint32_t acc_lo = 0, acc_hi = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)key[i], shift + k, 1);
+                    const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)w, shift + k, 1);
                     const unsigned long long b = __builtin_amdgcn_ballot_w64(B != 0u);
                     acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (uint32_t)b, B, 0xF6);
                     acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (uint32_t)(b >> 32), B, 0xF6);
@@ -1543,7 +1668,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
             // in every pass); they stay behind the n real keys, so validity is a property of the slot
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t d = (dword(i) >> shift) & 255u;
                 off[i] = 0;
                 if (my_base + i * 64u < n)
                     off[i] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1572,9 +1697,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
+            const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((dword(i) >> shift) & 255u)];
             if (RANK == 0 || my_base + i * 64u < n) {
                 s_stage[lpos] = key[i];
+                if constexpr (KW == 2) s_stage2[lpos] = keyh[i];
                 if constexpr (VB != 0) s_vstage[lpos] = val[i];
             }
         }
@@ -1582,6 +1708,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             key[i] = s_stage[my_base + i * 64u];
+            if constexpr (KW == 2) keyh[i] = s_stage2[my_base + i * 64u];
             if constexpr (VB != 0) val[i] = s_vstage[my_base + i * 64u];
         }
         // the next pass starts with a barrier (after zeroing whist) before anything writes the stage
@@ -1591,7 +1718,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
         const uint32_t idx = my_base + i * 64u;
         if (idx < n) {
             const uint32_t o = descending ? n - 1u - idx : idx;
-            keys[o] = from_bits<KT>(key[i]);
+            if constexpr (KW == 2) reinterpret_cast<uint2*>(keys)[o] = from_bits2<KT>(uint2{key[i], keyh[i]});
+            else keys[o] = from_bits<KT>(key[i]);
             if constexpr (VB != 0) reinterpret_cast<V*>(vals_)[o] = val[i];
         }
     }

@@ -27,6 +27,7 @@ from ._lib import check
 MODE_KEYS_ONLY, MODE_PAIRS = 0, 1
 ORDER_ASCENDING, ORDER_DESCENDING = 0, 1
 KEY_UINT32, KEY_INT32, KEY_FLOAT32 = 0, 1, 2
+KEY_UINT64, KEY_INT64, KEY_FLOAT64 = 3, 4, 5  # 8-byte keys: two stable 4-pass rounds (low word, high word)
 PAYLOAD_UINT32, PAYLOAD_INT32, PAYLOAD_FLOAT32 = 0, 1, 2
 ENTROPY_PRESET_1, ENTROPY_PRESET_2, ENTROPY_PRESET_3, ENTROPY_PRESET_4, ENTROPY_PRESET_5 = range(5)
 _ENT_LOOKUP = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201
@@ -154,9 +155,13 @@ class OneSweep:
         """Identity passes (one digit value for all keys) are dropped in pairs on the device (default on)."""
         check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")
 
+    @property
+    def key_bytes(self) -> int:
+        return 8 if self.key_type >= KEY_UINT64 else 4
+
     def _alts(self, n: int, values: torch.Tensor | None):
-        if self._alt_keys is None or self._alt_keys.numel() < n:
-            self._alt_keys = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        if self._alt_keys is None or self._alt_keys.numel() < n or self._alt_keys.element_size() != self.key_bytes:
+            self._alt_keys = torch.empty(max(n, 1), dtype=torch.int64 if self.key_bytes == 8 else torch.int32, device=self.device)
         if values is not None and (self._alt_vals is None or self._alt_vals.numel() < n
                                    or self._alt_vals.element_size() != values.element_size()):
             dt = torch.int32 if values.element_size() == 4 else torch.int64
@@ -173,8 +178,8 @@ class OneSweep:
         """
         _require_cuda(keys, "keys")
         n = keys.numel() if n is None else int(n)
-        if keys.element_size() != 4:
-            raise ValueError("keys must be a 32-bit type")
+        if keys.element_size() != self.key_bytes:
+            raise ValueError(f"keys must be a {8 * self.key_bytes}-bit type for this sorter's key type")
         if (values is not None) != (self.mode == MODE_PAIRS):
             raise ValueError("values must be given exactly when the sorter was built with MODE_PAIRS")
         _require_room(keys, n, "keys")
@@ -187,7 +192,7 @@ class OneSweep:
                 alt_values = own_alt_vals
         _require_room(alt_keys, n, "alt_keys")
         _require_room(alt_values if values is not None else None, n, "alt_values")
-        if alt_keys.element_size() != 4 or (values is not None and alt_values.element_size() != values.element_size()):
+        if alt_keys.element_size() != self.key_bytes or (values is not None and alt_values.element_size() != values.element_size()):
             raise ValueError("alt buffers must have the element size of the buffers they shadow")
         s = _stream_ptr(stream)
         if values is None:

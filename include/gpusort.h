@@ -48,7 +48,14 @@ typedef enum gs_mode { GS_MODE_KEYS_ONLY = 0, GS_MODE_PAIRS = 1 } gs_mode;
 /* GPUSortingD3D12/GPUSorting.h:47-52 */
 typedef enum gs_order { GS_ORDER_ASCENDING = 0, GS_ORDER_DESCENDING = 1 } gs_order;
 /* GPUSortingD3D12/GPUSorting.h:54-60 */
-typedef enum gs_key_type { GS_KEY_UINT32 = 0, GS_KEY_INT32 = 1, GS_KEY_FLOAT32 = 2 } gs_key_type;
+typedef enum gs_key_type {
+    GS_KEY_UINT32 = 0, GS_KEY_INT32 = 1, GS_KEY_FLOAT32 = 2,
+    /* 64-bit keys (the reference has 32-bit keys only): 8-byte elements in d_keys / d_alt, sorted in
+     * two stable 4-pass rounds (low word, then high word) of the same kernels; values as for 32-bit keys.  Accepted by
+     * gs_onesweep_sort_keys / _sort_pairs / _digit_pass (pass 0..7); not by the histogram read-back, the MSD split
+     * and the fixtures, which are 32-bit. */
+    GS_KEY_UINT64 = 3, GS_KEY_INT64 = 4, GS_KEY_FLOAT64 = 5
+} gs_key_type;
 /* GPUSortingCUDA/UtilityKernels.cuh:16-24 (value = number of extra AND-ed draws) */
 typedef enum gs_entropy_preset {
     GS_ENTROPY_PRESET_1 = 0, GS_ENTROPY_PRESET_2 = 1, GS_ENTROPY_PRESET_3 = 2,

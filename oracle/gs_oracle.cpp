@@ -187,6 +187,53 @@ void gso_std_sort(uint32_t* keys, void* vals, uint32_t value_bytes, uint32_t n, 
     }
 }
 
+uint64_t gso_key64_to_bits(uint64_t u, int key_type) {
+    /* the 32-bit rules of SortCommon.hlsl:134-154 on the 64-bit pattern */
+    switch (key_type) {
+        case GSO_KEY_I32: return u ^ 0x8000000000000000ull;
+        case GSO_KEY_F32: return u ^ ((uint64_t)(-(int64_t)(u >> 63)) | 0x8000000000000000ull);
+        default: return u;
+    }
+}
+
+void gso_std_sort64(uint64_t* keys, void* vals, uint32_t value_bytes, uint32_t n, int key_type, int order) {
+    /* 64-bit keys (not in the reference): the same definition as gso_std_sort — stable order by the
+     * radix-sortable bits, descending = exact reverse of the stable ascending result. */
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    std::vector<uint64_t> bits(n);
+    for (uint32_t i = 0; i < n; ++i) bits[i] = gso_key64_to_bits(keys[i], key_type);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return bits[a] < bits[b]; });
+    if (order == GSO_DESCENDING) std::reverse(idx.begin(), idx.end());
+    std::vector<uint64_t> k2(n);
+    for (uint32_t i = 0; i < n; ++i) k2[i] = keys[idx[i]];
+    std::memcpy(keys, k2.data(), sizeof(uint64_t) * n);
+    if (vals && value_bytes == 4) {
+        std::vector<uint32_t> v2(n);
+        for (uint32_t i = 0; i < n; ++i) v2[i] = ((uint32_t*)vals)[idx[i]];
+        std::memcpy(vals, v2.data(), sizeof(uint32_t) * n);
+    } else if (vals && value_bytes == 8) {
+        std::vector<uint64_t> v2(n);
+        for (uint32_t i = 0; i < n; ++i) v2[i] = ((uint64_t*)vals)[idx[i]];
+        std::memcpy(vals, v2.data(), sizeof(uint64_t) * n);
+    }
+}
+
+void gso_digit_binning_pass64(const uint64_t* kin, uint64_t* kout, const void* vin, void* vout, uint32_t value_bytes,
+                              uint32_t n, uint32_t shift, int key_type, int reverse_index) {
+    /* one stable 8-bit partition pass on bit position shift (0..56) of the sortable 64-bit pattern */
+    std::vector<uint32_t> pos(257, 0);
+    for (uint32_t i = 0; i < n; ++i) pos[((gso_key64_to_bits(kin[i], key_type) >> shift) & 255u) + 1]++;
+    for (int d = 0; d < 256; ++d) pos[d + 1] += pos[d];
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t dst = pos[(gso_key64_to_bits(kin[i], key_type) >> shift) & 255u]++;
+        if (reverse_index) dst = n - 1 - dst;
+        kout[dst] = kin[i];
+        if (vin && value_bytes == 4) ((uint32_t*)vout)[dst] = ((const uint32_t*)vin)[i];
+        if (vin && value_bytes == 8) ((uint64_t*)vout)[dst] = ((const uint64_t*)vin)[i];
+    }
+}
+
 void gso_std_sort_parallel(uint32_t* keys, uint32_t n, uint32_t threads) {
     if (threads < 2 || n < (1u << 16)) { std::sort(keys, keys + n); return; }
     /* round the chunk count down to a power of two so the merge tree is regular */

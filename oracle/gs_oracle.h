@@ -92,6 +92,13 @@ void gso_onesweep_sort(uint32_t* keys, uint32_t* alt_keys, void* vals, void* alt
 void gso_std_sort(uint32_t* keys, void* vals, uint32_t value_bytes, uint32_t n,
                   int key_type, int order);
 
+/* 64-bit keys (the reference sorts 32-bit keys only): the same definitions on 8-byte keys.
+ * key_type GSO_KEY_U32 / I32 / F32 here mean uint64 / int64 / float64. */
+uint64_t gso_key64_to_bits(uint64_t native_bits, int key_type);
+void gso_std_sort64(uint64_t* keys, void* vals, uint32_t value_bytes, uint32_t n, int key_type, int order);
+void gso_digit_binning_pass64(const uint64_t* keys_in, uint64_t* keys_out, const void* vals_in, void* vals_out,
+                              uint32_t value_bytes, uint32_t n, uint32_t shift, int key_type, int reverse_index);
+
 /* Multi-threaded variant for the cpu_baseline leg: chunked std::sort + merge
  * tree on `threads` host threads (keys only, u32 ascending). */
 void gso_std_sort_parallel(uint32_t* keys, uint32_t n, uint32_t threads);

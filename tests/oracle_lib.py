@@ -43,6 +43,10 @@ class Oracle:
         lib.gso_std_sort_parallel.restype = None
         lib.gso_sort_permutation_parallel.argtypes = [v, u32, i, i, u32, v]
         lib.gso_sort_permutation_parallel.restype = None
+        lib.gso_std_sort64.argtypes = [v, v, u32, u32, i, i]
+        lib.gso_std_sort64.restype = None
+        lib.gso_digit_binning_pass64.argtypes = [v, v, v, v, u32, u32, u32, i, i]
+        lib.gso_digit_binning_pass64.restype = None
         lib.gso_validate.argtypes = [v, v, u32, u32, i, i]
         lib.gso_validate.restype = u32
         lib.gso_msd_splitters.argtypes = [v, u32, v]
@@ -95,6 +99,20 @@ class Oracle:
         v = None if vals is None else vals.copy()
         self.lib.gso_std_sort(self._p(k), self._p(v), self._vb(vals), k.size, key_type, order)
         return k if vals is None else (k, v)
+
+    def std_sort64(self, keys, key_type=KEY_U32, order=ASC, vals=None):
+        """64-bit keys (uint64 array of native bit patterns); key_type 0/1/2 = uint64 / int64 / float64."""
+        k = keys.copy()
+        v = None if vals is None else vals.copy()
+        self.lib.gso_std_sort64(self._p(k), self._p(v), self._vb(vals), k.size, key_type, order)
+        return k if vals is None else (k, v)
+
+    def digit_pass64(self, keys, shift, key_type=KEY_U32, vals=None, reverse=False):
+        ko = np.empty_like(keys)
+        vo = None if vals is None else np.empty_like(vals)
+        self.lib.gso_digit_binning_pass64(self._p(keys), self._p(ko), self._p(vals), self._p(vo), self._vb(vals),
+                                          keys.size, shift, key_type, 1 if reverse else 0)
+        return ko if vals is None else (ko, vo)
 
     def std_sort_parallel(self, keys, threads):
         k = keys.copy()

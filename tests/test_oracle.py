@@ -251,3 +251,29 @@ def test_sort_permutation_parallel_is_the_stable_sort(oracle, kt, order):
     rk, rv = oracle.std_sort(keys, kt, order, np.arange(n, dtype=np.uint32))
     np.testing.assert_array_equal(perm, rv)
     np.testing.assert_array_equal(keys[perm], rk)
+
+
+def test_oracle_64bit_keys_against_numpy(oracle):
+    """The 64-bit definitions the keys64 GPU tests check against: uint64 / int64 / float64 order, descending =
+    reverse, stability, and eight stable byte passes == the sort."""
+    rng = np.random.default_rng(3)
+    n = 50021
+    k = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    np.testing.assert_array_equal(oracle.std_sort64(k), np.sort(k))
+    np.testing.assert_array_equal(oracle.std_sort64(k, 1).view(np.int64), np.sort(k.view(np.int64)))
+    f = rng.standard_normal(n) * 1e100
+    np.testing.assert_array_equal(oracle.std_sort64(f.view(np.uint64), 2).view(np.float64), np.sort(f))
+    np.testing.assert_array_equal(oracle.std_sort64(f.view(np.uint64), 2, 1).view(np.float64), np.sort(f)[::-1])
+    d = rng.integers(0, 5, size=n, dtype=np.uint64) << np.uint64(40)
+    v = np.arange(n, dtype=np.uint32)
+    rk, rv = oracle.std_sort64(d, 0, 0, v)
+    perm = np.argsort(d, kind="stable")
+    np.testing.assert_array_equal(rv, perm.astype(np.uint32))
+    rk2, rv2 = oracle.std_sort64(d, 0, 1, v)
+    np.testing.assert_array_equal(rv2, perm[::-1].astype(np.uint32))
+    c, cv = k.copy(), v.copy()
+    for p in range(8):
+        c, cv = oracle.digit_pass64(c, 8 * p, 0, cv)
+    ek, ev = oracle.std_sort64(k, 0, 0, v)
+    np.testing.assert_array_equal(c, ek)
+    np.testing.assert_array_equal(cv, ev)
