@@ -47,6 +47,7 @@ _PROTOS = [
     ("gs_onesweep_set_rank_mode", _int, [_vp, _int]),
     ("gs_onesweep_set_small_path", _int, [_vp, _int]),
     ("gs_onesweep_set_skip_passes", _int, [_vp, _int]),
+    ("gs_onesweep_set_mid_path", _int, [_vp, _int]),
     ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_copy_floor", _int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("gs_debug_set_trace", _int, [_vp, _vp]),

@@ -13,6 +13,7 @@
 //   - everything is enqueued on the caller's stream.
 #include "../../include/gpusort.h"
 #include "onesweep_kernels.hpp"
+#include "mid_kernels.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -116,6 +117,7 @@ struct gs_onesweep {
     int shape;
     int shape_auto;  // 1 = the library picks (mid sizes use MID_SHAPE); 0 after gs_onesweep_set_shape / GPUSORT_SHAPE
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
+    int mid_path;    // 1 = two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (default), 0 = the six-launch path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int heavy;       // heavy-value position slices in keys-only sorts: 1 on (default), 0 off
     uint32_t heavy_min_keys;  // ... from this many keys up (default 2^26; GPUSORT_HEAVY_MIN_LOG2, floor 2^22 in the kernel)
@@ -235,6 +237,20 @@ inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_k
     return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
 }
 
+// mid sizes: two launches (mid_kernels.hpp).  [rank mode][vb index][key type]
+using MidLauncher = void (*)(hipStream_t, uint32_t tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch,
+                             uint32_t* status, uint32_t n, uint32_t descending);
+template <int VB, int KT, int RANK>
+void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch, uint32_t* status,
+                uint32_t n, uint32_t descending) {
+    hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK>), dim3(tiles), dim3(gs::MID_THREADS), 0, s, keys, alt, vals, valt, scratch, status, n,
+                       descending);
+    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK>), dim3(gs::RADIX), dim3(gs::MID_THREADS), 0, s, keys, alt, vals, valt, scratch, n,
+                       descending);
+}
+#define GS_MID_ROW(VB, R) {launch_mid<VB, 0, R>, launch_mid<VB, 1, R>, launch_mid<VB, 2, R>}
+const MidLauncher g_mid[2][3][3] = {{GS_MID_ROW(0, 0), GS_MID_ROW(4, 0), GS_MID_ROW(8, 0)}, {GS_MID_ROW(0, 1), GS_MID_ROW(4, 1), GS_MID_ROW(8, 1)}};
+
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
     if (SmallLauncher small = h->small_path ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
@@ -247,6 +263,19 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         h->profile_pending = h->profiling != 0;
         // the scan state is untouched, so a later gs_onesweep_check() still reads the last tiled sort's word;
         // the single-tile kernel has no spin and cannot time out
+        return GS_OK;
+    }
+    if (h->mid_path && h->shape_auto && n <= gs::MID_MAX_KEYS && !is_key64(kt)) {
+        // one MSD pass + one LDS sort per top-byte bucket (a skewed top byte: the LSD passes inside the first kernel)
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
+        g_mid[h->rank_mode][vb_index(vb)][kt](s, div_up(n, gs::MID_TILE), static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys),
+                                              d_vals, d_alt_vals, h->slab + gs::SLAB_MID, h->slab + SLAB_STATUS, n,
+                                              order == GS_ORDER_DESCENDING ? 1u : 0u);
+        h->last_tile = 0;
+        if (h->profiling)  // everything is charged to slot 0 (and the total)
+            for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
+        GS_HIP(hipGetLastError());
+        h->profile_pending = h->profiling != 0;
         return GS_OK;
     }
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
@@ -369,6 +398,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     if (const char* env = getenv("GPUSORT_HEAVY")) h->heavy = atoi(env) ? 1 : 0;
     h->skip_passes = 1;
     if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
+    h->mid_path = 1;
+    if (const char* env = getenv("GPUSORT_MID_PATH")) h->mid_path = atoi(env) ? 1 : 0;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
@@ -436,6 +467,12 @@ gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf) {  // experiment build
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on) {
     if (!h) return GS_ERR_ARG;
     h->small_path = on ? 1 : 0;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_mid_path(gs_onesweep* h, int on) {
+    if (!h) return GS_ERR_ARG;
+    h->mid_path = on ? 1 : 0;
     return GS_OK;
 }
 

@@ -171,8 +171,12 @@ constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
 constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + 4 * NCH * RADIX;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
-constexpr uint32_t SLAB_DESC = SLAB_HSUB + 4 * HSUB_STRIDE;
-static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
+// MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): barrier counter, route flag, bucket table,
+// two count tables of MID_MAX_TILES rows
+constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
+constexpr uint32_t SLAB_MID_WORDS = 64 + 2 * RADIX + 2 * 128 * RADIX;
+constexpr uint32_t SLAB_DESC = SLAB_MID + SLAB_MID_WORDS;
+static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif

@@ -151,6 +151,10 @@ class OneSweep:
     def set_small_path(self, on: bool) -> None:
         check(self._lib.gs_onesweep_set_small_path(self._h, 1 if on else 0), "gs_onesweep_set_small_path")
 
+    def set_mid_path(self, on: bool) -> None:
+        """Two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (default on)."""
+        check(self._lib.gs_onesweep_set_mid_path(self._h, 1 if on else 0), "gs_onesweep_set_mid_path")
+
     def set_skip_passes(self, on: bool) -> None:
         """Identity passes (one digit value for all keys) are dropped in pairs on the device (default on)."""
         check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")

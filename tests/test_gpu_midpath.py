@@ -1,0 +1,149 @@
+"""The two-launch sort of mid-size inputs (single-tile limit < n <= 2^20; gpusorting_amd/csrc/mid_kernels.hpp):
+one MSD pass on the top byte + one LDS sort per top-byte bucket, and — when a bucket would not fit a workgroup — the
+four LSD passes inside the first kernel.  SURVEY.md §8f N1; the reference's size sweep is
+GPUSortingD3D12/Tests.h:392-393,415-416 and Unity's ladder GPUSortingUnity/Tests/TestBase.cs:238-264.  Every case
+is bit-exact against the oracle with value = original index, and equal to the general six-launch path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(a.view(np.int64 if a.dtype.itemsize == 8 else np.int32)).cuda()
+
+
+def _sort(gpu, s, keys, vals):
+    dk = _dev(keys)
+    dv = None if vals is None else _dev(vals)
+    s.sort(dk, dv)
+    s.check()
+    return dk.cpu().numpy().view(np.uint32), (None if vals is None else dv.cpu().numpy().view(vals.dtype))
+
+
+def _keys(oracle, rng, n, kind):
+    if kind == "uniform":
+        return oracle.init_random(n, n + 1, 0)
+    if kind == "preset4":                      # AND of 4 draws: the top byte is 0 for 59 % of the keys
+        return oracle.init_random(n, n + 2, 3)
+    if kind == "top-constant":                 # one bucket holds everything: the LSD route whenever n > 8192
+        return oracle.init_random(n, n + 3, 0) & np.uint32(0x00FFFFFF) | np.uint32(0x5A000000)
+    if kind == "low-constant":                 # buckets of identical low bits: three identity passes in every bucket
+        return (rng.integers(0, 256, size=n, dtype=np.uint32) << np.uint32(24)) | np.uint32(0x00123456)
+    if kind == "two-values":
+        return np.where(rng.integers(0, 2, size=n) == 1, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32)
+    raise ValueError(kind)
+
+
+SIZES = (8193, 12000, 16385, 32769, 40000, 65536, 100003, (1 << 18) + 1, (1 << 19) + 5, 1 << 20)
+
+
+@pytest.mark.parametrize("vb", [0, 4, 8])
+@pytest.mark.parametrize("kind", ["uniform", "preset4", "top-constant", "low-constant", "two-values"])
+def test_mid_path_sizes_and_distributions(gpu, oracle, vb, kind):
+    rng = np.random.default_rng(17 + vb)
+    for n in SIZES:
+        keys = _keys(oracle, rng, n, kind)
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ref = oracle.std_sort(keys, 0, 0, vals)
+        rk, rv = (ref, None) if vals is None else ref
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        for mid in (True, False, True):        # the same handle alternates between the two routes
+            s.set_mid_path(mid)
+            ok, ov = _sort(gpu, s, keys, vals)
+            np.testing.assert_array_equal(ok, rk, err_msg=f"{kind} n={n} vb={vb} mid={mid}")
+            if vb:
+                np.testing.assert_array_equal(ov, rv, err_msg=f"{kind} values n={n} vb={vb} mid={mid}")
+        s.close()
+
+
+@pytest.mark.parametrize("kt", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("rank", [0, 1])
+def test_mid_path_types_orders_rank_modes(gpu, oracle, kt, order, rank):
+    rng = np.random.default_rng(5)
+    for n, kind in ((20001, "uniform"), (300007, "uniform"), (70000, "preset4"), (50000, "top-constant")):
+        keys = _keys(oracle, rng, n, kind)
+        vals = np.arange(n, dtype=np.uint32)
+        s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS, 4)
+        s.set_rank_mode(rank)
+        ok, ov = _sort(gpu, s, keys, vals)
+        rk, rv = oracle.std_sort(keys, kt, order, vals)
+        np.testing.assert_array_equal(ok, rk, err_msg=f"{kind} n={n} kt={kt} order={order} rank={rank}")
+        np.testing.assert_array_equal(ov, rv, err_msg=f"{kind} values n={n} kt={kt} order={order} rank={rank}")
+        s.close()
+
+
+def test_mid_path_bucket_capacity_boundary(gpu, oracle):
+    """A top-byte bucket of exactly 8192 keys is sorted by one workgroup (MSD route); one key more and the first
+    kernel runs the LSD passes instead.  Both must be exact."""
+    rng = np.random.default_rng(9)
+    for heavy in (8191, 8192, 8193, 9000):
+        n = 30000
+        keys = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+        keys = np.where(keys >> 24 == 7, keys ^ np.uint32(0x01000000), keys)      # nobody has top byte 7 ...
+        keys[:heavy] = (keys[:heavy] & np.uint32(0x00FFFFFF)) | np.uint32(0x07000000)  # ... but exactly `heavy` keys
+        rng.shuffle(keys)
+        vals = np.arange(n, dtype=np.uint32)
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS, value_bytes=4)
+        ok, ov = _sort(gpu, s, keys, vals)
+        rk, rv = oracle.std_sort(keys, 0, 0, vals)
+        np.testing.assert_array_equal(ok, rk, err_msg=f"heavy={heavy}")
+        np.testing.assert_array_equal(ov, rv, err_msg=f"heavy={heavy} values")
+        s.close()
+
+
+def test_mid_path_repeated_and_graph_replay(gpu, oracle):
+    """The grid-barrier counter goes back to zero with every sort: many sorts on one handle, and a captured sort
+    replayed from a HIP graph."""
+    import torch
+    n = 200003
+    s = gpu.OneSweep(n)
+    for it in range(20):
+        keys = oracle.init_random(n, 100 + it, it % 5)
+        ok, _ = _sort(gpu, s, keys, None)
+        np.testing.assert_array_equal(ok, oracle.std_sort(keys), err_msg=f"iteration {it}")
+    work = torch.empty(n, dtype=torch.int32, device="cuda")
+    alt = torch.empty_like(work)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s.sort(work, alt_keys=alt)          # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        s.sort(work, alt_keys=alt)
+    for seed in (3, 4, 5):
+        keys = oracle.init_random(n, seed, 0 if seed != 5 else 4)
+        work.copy_(torch.from_numpy(keys.view(np.int32)))
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(work.cpu().numpy().view(np.uint32), oracle.std_sort(keys), err_msg=f"replay seed {seed}")
+    s.close()
+
+
+def test_mid_path_latency_for_the_record(gpu, oracle):
+    """Microseconds per sort at 2^16 and 2^20 keys, both routes (printed with -s; no assertion on speed)."""
+    import torch
+    for lg in (14, 16, 18, 20):
+        n = 1 << lg
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        alt = torch.empty_like(dk)
+        for mid in (True, False):
+            s = gpu.OneSweep(n)
+            s.set_mid_path(mid)
+            times = []
+            for r in range(12):
+                gpu.init_random(dk, 10 + r, 0)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                s.sort(dk, alt_keys=alt)
+                b.record()
+                b.synchronize()
+                times.append(a.elapsed_time(b) * 1e3)
+            assert gpu.validate(dk) == 0
+            print(f"2^{lg} keys, {'two-launch' if mid else 'six-launch'} path: {sorted(times)[len(times) // 2]:.1f} us per sort (median of 12)")
+            s.close()

@@ -27,6 +27,16 @@ def to_host(t, dtype):
     return t.cpu().numpy().view(dtype)
 
 
+@pytest.fixture(autouse=True, params=["default-routing", "general-path"])
+def routing(request, monkeypatch):
+    """Every test of this file runs twice: with the library's own routing (single-tile kernel for small n, the
+    two-launch MSD + bucket sort up to 2^20 keys, the six-launch pipeline above) and with the mid-size route
+    switched off, so that the general pipeline stays covered at the sizes the mid-size route now takes."""
+    if request.param == "general-path":
+        monkeypatch.setenv("GPUSORT_MID_PATH", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def P(gpu):
     s = gpu.OneSweep(1 << 16)
@@ -116,6 +126,7 @@ def test_gpu_matches_reference_kernel_vectors(gpu):
             ck, cv = ok, ov
         for small in (True, False):                         # the complete sort, both small-n routes
             s.set_small_path(small)
+            s.set_mid_path(small)
             fk, fv = dk.clone(), (None if dv is None else dv.clone())
             s.sort(fk, fv)
             s.check()
@@ -414,6 +425,7 @@ def test_single_tile_path_and_tiled_path_agree(gpu, oracle, small_path, vb, kt, 
         vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
         s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
         s.set_small_path(small_path)
+        s.set_mid_path(small_path)
         for rank in (0, 1):
             s.set_rank_mode(rank)
             dk = to_dev(keys)
@@ -773,6 +785,7 @@ def test_scan_state_invariants(gpu, oracle):
                               (700001, 0, 8, 0x0000FFFF), (5000, 0, 0, 0xFFFFFFFF)]:
         keys = oracle.init_random(n, 5 + andc, andc) & np.uint32(mask)
         s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        s.set_mid_path(False)  # the scan state of the general pipeline is what this test looks at
         dk = to_dev(keys)
         dv = None if not vb else torch.arange(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
         s.sort(dk, dv)
