@@ -253,7 +253,11 @@ const MidLauncher g_mid[2][3][3] = {{GS_MID_ROW(0, 0), GS_MID_ROW(4, 0), GS_MID_
 
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
-    if (SmallLauncher small = h->small_path ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
+    // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20; the general
+    // pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
+    // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
+    const bool use_mid = h->mid_path && h->shape_auto && n > gs::SMALL_TILE && n <= gs::MID_MAX_KEYS && !is_key64(kt);
+    if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
         h->last_tile = 0;
@@ -265,7 +269,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         // the single-tile kernel has no spin and cannot time out
         return GS_OK;
     }
-    if (h->mid_path && h->shape_auto && n <= gs::MID_MAX_KEYS && !is_key64(kt)) {
+    if (use_mid) {
         // one MSD pass + one LDS sort per top-byte bucket (a skewed top byte: the LSD passes inside the first kernel)
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         g_mid[h->rank_mode][vb_index(vb)][kt](s, div_up(n, gs::MID_TILE), static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys),
