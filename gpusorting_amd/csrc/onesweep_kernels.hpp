@@ -113,6 +113,12 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 #ifndef GS_FUSED_PAIRS
 #define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
 #endif
+#ifndef GS_SCALAR_LOOKBACK
+#define GS_SCALAR_LOOKBACK 0  // 1 = descriptor rows are polled through the scalar data path first (experiment)
+#endif
+#ifndef GS_SCALAR_POLLS
+#define GS_SCALAR_POLLS 64
+#endif
 #ifndef GS_WALK_ROWS
 #define GS_WALK_ROWS 1  // descriptor rows per round trip of the look-back walk.  Measured in round 2 (profiles/
                         // r02_ab_early_lookback_rows.txt): 4 rows per trip +3 %; 4 / 8 / 16 rows requested BEFORE the
@@ -272,6 +278,25 @@ __device__ __forceinline__ uint2 ld_stream(const uint2* p) {
 }
 __device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
     st_stream(reinterpret_cast<u32x2_t*>(p), u32x2_t{v.x, v.y});
+}
+
+// 64 consecutive descriptor words, one per lane, through the SCALAR data path (s_load ... glc: served by L2, not
+// queued behind the CU's vector memory traffic — the look-back's dependent round trips otherwise wait ~0.5 us each
+// behind the workgroups' own key loads and stores).  p is wave-uniform and 64-byte aligned.
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t sload_row64(const uint32_t* p) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // 32 words at a time: 32 scalar registers in flight, not 64
+        u32x16_t a, b;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(a), "=&s"(b) : "s"(p + 32 * h) : "memory");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(a[j]), "n"(32 * h + j));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(b[j]), "n"(32 * h + 16 + j));
+    }
+    return v;
 }
 
 template <int N>
@@ -1280,8 +1305,44 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             }
         }
     };
+#if GS_SCALAR_LOOKBACK
+    // The same walk with the rows fetched through the scalar data path.  A scalar load is wave-uniform, so the four
+    // look-back waves each read ONE row per trip — the highest row any of their 64 digits still needs (digits of a
+    // wave move in step: a tile publishes all 256 words of a row together) — and every digit waiting for exactly that
+    // row consumes its word.  After GS_SCALAR_POLLS polls without progress a wave goes on with the vector form below
+    // (its own path through the memory system, and the one the bounded-spin / fallback logic is written for).
+    auto walk_scalar = [&]() {
+        uint32_t idle = 0;
+        for (;;) {  // wave-uniform loop
+            const unsigned long long open = __builtin_amdgcn_ballot_w64(!done);
+            if (!open) return;
+            // highest row wanted: digits are in step or at most a few rows apart
+            int32_t r = (int32_t)__builtin_amdgcn_readlane((uint32_t)k, (uint32_t)__builtin_ctzll(open));
+            for (;;) {
+                const unsigned long long above = __builtin_amdgcn_ballot_w64(!done && k > r);
+                if (!above) break;
+                r = (int32_t)__builtin_amdgcn_readlane((uint32_t)k, (uint32_t)__builtin_ctzll(above));
+            }
+            GS_TRACE_TRIP();
+            const uint32_t v = sload_row64(cdesc + (size_t)uni((uint32_t)r) * RADIX + uni(tid & ~63u));
+            bool progressed = false;
+            if (!done && k == r) {
+                const uint32_t f = v & FLAG_MASK;
+                if (f == FLAG_INCLUSIVE) { prev += v >> 2; done = true; progressed = true; }
+                else if (f == FLAG_REDUCTION) { prev += v >> 2; --k; progressed = true; }
+                else if (f == FLAG_POISON) { poisoned = true; done = true; progressed = true; }
+            }
+            if (__builtin_amdgcn_ballot_w64(progressed)) { idle = 0; continue; }
+            if (++idle > GS_SCALAR_POLLS) return;  // stuck on this row: the vector walk takes over (spin bounds, fallback)
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+#endif
     GS_TRACE(4);
     GS_ABL_ASSUME_PREV();
+#if GS_SCALAR_LOOKBACK
+    if (!finished) walk_scalar();  // whole waves: tid < RADIX
+#endif
     for (;;) {
         if (!finished) {
 #if GS_ADAPTIVE_BATCH
