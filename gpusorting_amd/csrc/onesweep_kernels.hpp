@@ -83,17 +83,6 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #endif
 // (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
 //  returns a not-yet-final row and the wait moves in front of staging)
-#ifndef GS_ADAPTIVE_BATCH
-#define GS_ADAPTIVE_BATCH 0  // 1 = a chain holding a large share of the pass's tiles (skewed digit groups) fetches 4 or
-                             // 16 rows per look-back round trip.  Measured: -3 % on the worst presets (the wait in a
-                             // crowded chain is for predecessors to publish at all, not for the walk), while the two
-                             // extra unrolled walks cost the uniform case 1-2 % in code size alone.  Off.
-#endif
-#ifndef GS_NB_HEAVY
-#define GS_NB_HEAVY 16u  // rows per round trip in a chain that holds at least half of the pass's tiles (64 measured
-                         // worse: 9.8 us look-back per tile vs 6.6 — the wait in a crowded chain is for predecessors
-                         // to publish at all, not for the walk; see DESIGN.md on skew)
-#endif
 #ifndef GS_FALLBACK
 #define GS_FALLBACK 1  // a look-back that waited FALLBACK_SPINS polls on one row recounts that tile's digits itself
                        // (whole workgroup, from the pass input) and goes on: no tile ever depends on another
@@ -113,20 +102,11 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 #ifndef GS_FUSED_PAIRS
 #define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
 #endif
-#ifndef GS_SCALAR_LOOKBACK
-#define GS_SCALAR_LOOKBACK 0  // 1 = descriptor rows are polled through the scalar data path first (experiment)
-#endif
-#ifndef GS_SCALAR_POLLS
-#define GS_SCALAR_POLLS 64
-#endif
 #ifndef GS_WALK_ROWS
 #define GS_WALK_ROWS 1  // descriptor rows per round trip of the look-back walk.  Measured in round 2 (profiles/
                         // r02_ab_early_lookback_rows.txt): 4 rows per trip +3 %; 4 / 8 / 16 rows requested BEFORE the
                         // staging phase and consumed after it +3 / +5 / +6 % — an INCLUSIVE row is further back than that
                         // when the request is issued, so the walk repeats the reads and the chip only moved more bytes
-#endif
-#ifndef GS_ONEWAVE_REDUCE
-#define GS_ONEWAVE_REDUCE 0  // (measured: no gain over the four-wave form, profiles/r02_ab_onewave_exp1.txt) 1 = the per-tile digit fold (prefix over waves, totals, 256-digit scan) by one wave on 16-byte LDS accesses
 #endif
 #ifndef GS_HEAVY_SHARE
 #define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
@@ -278,25 +258,6 @@ __device__ __forceinline__ uint2 ld_stream(const uint2* p) {
 }
 __device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
     st_stream(reinterpret_cast<u32x2_t*>(p), u32x2_t{v.x, v.y});
-}
-
-// 64 consecutive descriptor words, one per lane, through the SCALAR data path (s_load ... glc: served by L2, not
-// queued behind the CU's vector memory traffic — the look-back's dependent round trips otherwise wait ~0.5 us each
-// behind the workgroups' own key loads and stores).  p is wave-uniform and 64-byte aligned.
-typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ uint32_t sload_row64(const uint32_t* p) {
-    uint32_t v = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {  // 32 words at a time: 32 scalar registers in flight, not 64
-        u32x16_t a, b;
-        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(a), "=&s"(b) : "s"(p + 32 * h) : "memory");
-#pragma unroll
-        for (int j = 0; j < 16; ++j) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(a[j]), "n"(32 * h + j));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(b[j]), "n"(32 * h + 16 + j));
-    }
-    return v;
 }
 
 template <int N>
@@ -1126,55 +1087,6 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     uint32_t tile_total = 0, scan_incl = 0, dpre = 0, dummies = 0;
     // the tile's trailing dummies are not ranked (and later not staged) in the plain LDS-atomic ranking path
     const bool tail_unranked = RANK == 1 && !full && (pflags & PF_SKEW) == 0u;
-#if GS_ONEWAVE_REDUCE
-    // ONE wave does the whole fold, four digits per lane on 16-byte LDS accesses: exclusive prefix over the
-    // waves, tile totals (published as REDUCTION with two 8-byte sc1 stores per lane: the row is 1 KiB
-    // contiguous), the 256-digit scan on the VALU (DPP), the stage offsets folded back into the per-wave
-    // bases.  One barrier instead of two, 18 wide LDS operations instead of 128 dword ones, and no LDS
-    // round trips inside the scan.  The look-back threads pick their digit's total and offset up from LDS.
-    if (wave == 0) {
-        uint4 run4 = {0u, 0u, 0u, 0u};  // digit totals of the tile (dummies included)
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint4 t = reinterpret_cast<const uint4*>(s_whist + w * RADIX)[lane];
-            run4.x += t.x; run4.y += t.y; run4.z += t.z; run4.w += t.w;
-            if (w == WAVES / 2 - 1) asm volatile("" ::: "memory");  // two batches of reads in flight, not all rows: registers
-        }
-        uint4 tt = run4;  // real keys only (see the dword form below)
-        if (lane == 0) tt.x -= head;
-        if (lane == 63 && !full && !tail_unranked) tt.w -= TILE - head - count;
-        if (!GS_FAULT_TILE(chain, tile)) {
-            unsigned long long* row = reinterpret_cast<unsigned long long*>(&cdesc[(size_t)(tile + 1u) * RADIX + 4u * lane]);
-            __hip_atomic_store(row, (unsigned long long)((tt.x << 2) | FLAG_REDUCTION) | ((unsigned long long)((tt.y << 2) | FLAG_REDUCTION) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(row + 1, (unsigned long long)((tt.z << 2) | FLAG_REDUCTION) | ((unsigned long long)((tt.w << 2) | FLAG_REDUCTION) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const uint32_t lane_sum = run4.x + run4.y + run4.z + run4.w;
-        const uint32_t excl = wave_inclusive_scan_dpp(lane_sum) - lane_sum;
-        const uint4 dp = {excl, excl + run4.x, excl + run4.x + run4.y, excl + run4.x + run4.y + run4.z};
-        reinterpret_cast<uint4*>(s_dpre)[lane] = dp;
-        reinterpret_cast<uint4*>(s_gbase)[lane] = tt;  // parked here until the look-back overwrites it with the base
-        // second sweep over the per-wave counts (re-read: keeping all eight rows in registers next to the tile's
-        // keys spilled): count -> stage offset of (wave, digit) = digit offset + counts of the waves in front
-        uint4 acc = dp;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            uint4* row = reinterpret_cast<uint4*>(s_whist + w * RADIX) + lane;
-            const uint4 t = *row;
-            *row = acc;
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            if (w == WAVES / 2 - 1) asm volatile("" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (tid < RADIX) {
-        tile_total = s_gbase[tid];
-        dpre = s_dpre[tid];
-        dummies = (tid == 0 ? head : 0u) + ((tid == RADIX - 1 && !full && !tail_unranked) ? TILE - head - count : 0u);
-    }
-    (void)scan_incl;
-#else
     if (tid < RADIX) {
         uint32_t run = 0;
 #pragma unroll
@@ -1203,7 +1115,6 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
         for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
     }
     __syncthreads();
-#endif
 
     GS_TRACE(3);
     // ---- stage keys in LDS, sorted by digit (stable) ----
@@ -1256,17 +1167,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
 
     // ---- decoupled look-back inside the chain: one digit per thread ----
     // Row k holds tile k-1's descriptor; row 0 = chain base (INCLUSIVE), so every walk ends at row 0 at the
-    // latest.  NB rows are fetched per round trip: 1 in a balanced chain (walks are ~2 rows with 16 chains), 4 or
-    // 16 in a chain that holds a large share of the pass's tiles (skewed digit groups put most tiles in one
-    // chain; walk length grows with the chain's tile rate and shrinks with the rows in flight).
-    uint32_t nb = 1;
-#if GS_ADAPTIVE_BATCH
-    {
-        const uint32_t share = ((seg_end - (seg_start & ~63u) + TILE - 1) / TILE) * NCH;  // chain's tiles, in NCH-ths of the pass
-        const uint32_t all_tiles = (n + TILE - 1) / TILE;
-        nb = share >= 8u * all_tiles ? GS_NB_HEAVY : share >= 4u * all_tiles ? 16u : share >= 2u * all_tiles ? 4u : 1u;
-    }
-#endif
+    // latest.  One row per round trip (walks are ~3 rows with 16 chains).  Measured and not kept: more rows per trip,
+    // rows requested before the staging phase, rows through the scalar data path, larger batches in crowded chains
+    // (profiles/r02_ab_early_lookback_rows.txt, r02_ab_scalar_lookback.txt).
     uint32_t prev = 0, spins = 0;
     int32_t k = (int32_t)tile;
     bool done = GS_ABL_LOOKBACK_SKIPPED, poisoned = false, finished = tid >= RADIX;
@@ -1305,53 +1208,11 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             }
         }
     };
-#if GS_SCALAR_LOOKBACK
-    // The same walk with the rows fetched through the scalar data path.  A scalar load is wave-uniform, so the four
-    // look-back waves each read ONE row per trip — the highest row any of their 64 digits still needs (digits of a
-    // wave move in step: a tile publishes all 256 words of a row together) — and every digit waiting for exactly that
-    // row consumes its word.  After GS_SCALAR_POLLS polls without progress a wave goes on with the vector form below
-    // (its own path through the memory system, and the one the bounded-spin / fallback logic is written for).
-    auto walk_scalar = [&]() {
-        uint32_t idle = 0;
-        for (;;) {  // wave-uniform loop
-            const unsigned long long open = __builtin_amdgcn_ballot_w64(!done);
-            if (!open) return;
-            // highest row wanted: digits are in step or at most a few rows apart
-            int32_t r = (int32_t)__builtin_amdgcn_readlane((uint32_t)k, (uint32_t)__builtin_ctzll(open));
-            for (;;) {
-                const unsigned long long above = __builtin_amdgcn_ballot_w64(!done && k > r);
-                if (!above) break;
-                r = (int32_t)__builtin_amdgcn_readlane((uint32_t)k, (uint32_t)__builtin_ctzll(above));
-            }
-            GS_TRACE_TRIP();
-            const uint32_t v = sload_row64(cdesc + (size_t)uni((uint32_t)r) * RADIX + uni(tid & ~63u));
-            bool progressed = false;
-            if (!done && k == r) {
-                const uint32_t f = v & FLAG_MASK;
-                if (f == FLAG_INCLUSIVE) { prev += v >> 2; done = true; progressed = true; }
-                else if (f == FLAG_REDUCTION) { prev += v >> 2; --k; progressed = true; }
-                else if (f == FLAG_POISON) { poisoned = true; done = true; progressed = true; }
-            }
-            if (__builtin_amdgcn_ballot_w64(progressed)) { idle = 0; continue; }
-            if (++idle > GS_SCALAR_POLLS) return;  // stuck on this row: the vector walk takes over (spin bounds, fallback)
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-#endif
     GS_TRACE(4);
     GS_ABL_ASSUME_PREV();
-#if GS_SCALAR_LOOKBACK
-    if (!finished) walk_scalar();  // whole waves: tid < RADIX
-#endif
     for (;;) {
         if (!finished) {
-#if GS_ADAPTIVE_BATCH
-            if (GS_LIKELY(nb == 1u)) walk(IntTag<1>{});
-            else if (nb == 4u) walk(IntTag<4>{});
-            else walk(IntTag<16>{});
-#else
             walk(IntTag<GS_WALK_ROWS>{});
-#endif
             if (done) {
                 finished = true;
                 if (poisoned) {
