@@ -226,6 +226,7 @@ __global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, ui
     const uint32_t G = partition_step(24, table0, alive);
     if (!alive) return;
     const bool lsd_route = s_max > MID_BUCKET_CAP;  // the same table everywhere: the same decision everywhere
+    __syncthreads();  // everybody has read s_max before the next partition step resets it
     if (tile == 0 && tid < RADIX) {
         scratch[MID_BSTART + tid] = s_gbase[tid] + s_dpre[tid];  // tile 0 has no tile in front: its base IS the digit start
         scratch[MID_BCOUNT + tid] = G;
