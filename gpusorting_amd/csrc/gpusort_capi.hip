@@ -41,13 +41,17 @@ using BinLauncher = void (*)(hipStream_t, uint32_t grid, uint32_t*, uint32_t*, v
                              uint32_t* desc, uint32_t* counters, const uint32_t* info, uint32_t* hsub, uint32_t* status,
                              uint32_t n, uint32_t shift, uint32_t mode);
 
-template <int THREADS, int KPT, int VB, int KT, int RANK>
+template <int THREADS, int KPT, int VB, int KT, int RANK, int VR = 1>
 void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc,
                 uint32_t* counters, const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift,
                 uint32_t mode) {
-    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK>), dim3(grid), dim3(THREADS), 0, s, ka, kb,
+    hipLaunchKernelGGL((gs::digit_binning_kernel<THREADS, KPT, VB, KT, RANK, VR>), dim3(grid), dim3(THREADS), 0, s, ka, kb,
                        va, vb, desc, counters, info, hsub, status, n, shift, mode);
 }
+// the two-round form of the 8-byte-value pass (two workgroups per CU), launched beside the one-round form in full
+// sorts; the pass's PF_SKEW flag decides on the device which of the two works.  [rank mode][key type]
+const BinLauncher g_vr2[2][3] = {{launch_bin<512, 32, 8, 0, 0, 2>, launch_bin<512, 32, 8, 1, 0, 2>, launch_bin<512, 32, 8, 2, 0, 2>},
+                                 {launch_bin<512, 32, 8, 0, 1, 2>, launch_bin<512, 32, 8, 1, 1, 2>, launch_bin<512, 32, 8, 2, 1, 2>}};
 
 struct Shape {
     int threads, kpt;
@@ -310,9 +314,17 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         for (uint32_t p = 0; p < 4; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
             const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
+            // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
+            const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
             fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-               h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8, mode);
+               h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
+               mode | (two_forms ? 32u : 0u));
+            if (two_forms)
+                g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+                                        h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
+                                        h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
+                                        word * 32 + p * 8, mode | 16u);
             if (h->profiling && word == 0) GS_HIP(hipEventRecord(h->ev[4 + p], s));
         }
     }

@@ -702,7 +702,7 @@ struct ValT { using type = uint32_t; };
 template <>
 struct ValT<8> { using type = uint64_t; };
 
-template <int THREADS, int KPT, int VB, int KW = 1>
+template <int THREADS, int KPT, int VB, int KW = 1, int VR = 1>
 struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
@@ -711,7 +711,13 @@ struct BinCfg {
     // (8-byte values the same way need a 512 x 24 tile, 12 288 pairs x 12 B = 144 KiB in two LDS arrays: measured
     //  5.975 vs 6.014 ms, not worth a shape of its own; the code path stays generic in VB)
     static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4 && KW == 1;
-    static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : TILE * ((VB == 8 || KW == 2) ? 8 : 4);
+    // VR = 2: 8-byte values of 4-byte keys go through the stage in TWO rounds of TILE / 2 values: the stage stays at the
+    // 4 bytes per key the keys need, and a 16 384-pair tile leaves room for a second workgroup on the CU.  Measured
+    // (profiles/r02_ab_value_rounds.txt, 2^28 (u32, u64) pairs): uniform keys +5 % per pass (two predicated staging
+    // rounds, two more barriers), skewed keys -9 .. -13 % (the second workgroup covers the look-back waits of the
+    // crowded chain) — so both forms are compiled and the pass's PF_SKEW flag picks one on the device (mode bits 4, 5).
+    static constexpr int VROUNDS = (VR == 2 && VB == 8 && KW == 1 && !FUSED) ? 2 : 1;
+    static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : (VROUNDS == 2 ? TILE * 4 : TILE * ((VB == 8 || KW == 2) ? 8 : 4));
     // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
     static constexpr bool HEAVY = GS_HEAVY && VB == 0 && KW == 1;
     static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
@@ -730,8 +736,8 @@ struct BinCfg {
         WAVES_PER_SIMD_RAW < WAVES_PER_SIMD_CAP ? WAVES_PER_SIMD_RAW : WAVES_PER_SIMD_CAP;
 };
 
-template <int THREADS, int KPT, int VB, int KT, int RANK>
-__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value>::WAVES_PER_SIMD)) void digit_binning_kernel(
+template <int THREADS, int KPT, int VB, int KT, int RANK, int VR = 1>
+__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::WAVES_PER_SIMD)) void digit_binning_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b,  // the pass reads a and writes b, unless ...
     uint32_t* desc,          // this pass: rows of 256 descriptor words; chain x starts at row_base[x]
     uint32_t* counters,      // this pass: one ticket counter per chain
@@ -740,9 +746,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     uint32_t* status, uint32_t n, uint32_t shift_full /*bit position of the digit in the key: 0..24, 64-bit keys 0..56*/,
     uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
-                    on the last pass that runs (PF_LAST); bit2: zero the HIST region*/) {
+                    on the last pass that runs (PF_LAST); bit2: zero the HIST region; bit4 / bit5: this launch is one of two
+                    forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5)*/) {
     constexpr int KW = KeyWords<KT>::value;
-    using Cfg = BinCfg<THREADS, KPT, VB, KW>;
+    using Cfg = BinCfg<THREADS, KPT, VB, KW, VR>;
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
     constexpr uint32_t TILE = Cfg::TILE;
@@ -765,12 +772,16 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
                                                  // and of the keys below it in its digit group [256, 512)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
     if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
         constexpr uint32_t HWORDS = 4 * NCH * RADIX;
         const uint32_t i = blockIdx.x * THREADS + tid;
         if (i < HWORDS / 4) reinterpret_cast<uint4*>(hsub - HWORDS)[i] = uint4{0u, 0u, 0u, 0u};
     }
+    if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
+        const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
+        if (skewed != ((mode & 16u) != 0u)) return;
+    }
+    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
     if constexpr (Cfg::HEAVY)
         for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
     GS_TRACE_SETUP();
@@ -1413,31 +1424,50 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     if constexpr (VB != 0 && !Cfg::FUSED) {
         V* vals_out = reinterpret_cast<V*>(vals_out_);
         V* s_vstage = reinterpret_cast<V*>(s_raw);
-        __syncthreads();  // everyone is done reading the key stage
-        if (GS_LIKELY(!mask_tail)) {
+        constexpr int VRN = Cfg::VROUNDS;
+        constexpr uint32_t HALF = TILE / VRN;  // stage slots per round
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
-        } else {
+        for (int h = 0; h < VRN; ++h) {
+            __syncthreads();  // everyone is done reading the stage (the keys; the previous round's values)
+            if (GS_LIKELY(!mask_tail)) {
 #pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                if (my_base + i * 64u < hi) s_vstage[(offp[i >> 1] >> (16 * (i & 1))) & 0xffffu] = val[i];
-        }
-        __syncthreads();
-        if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
-            V vv[KPT];
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t pos = (offp[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                    if (VRN == 1 || pos / HALF == (uint32_t)h) s_vstage[pos - h * HALF] = val[i];
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) vv[j] = s_vstage[tid + j * THREADS];
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t pos = (offp[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                    if (my_base + i * 64u < hi && (VRN == 1 || pos / HALF == (uint32_t)h)) s_vstage[pos - h * HALF] = val[i];
+                }
+            }
+            __syncthreads();
+            constexpr int J0 = 0, JN = KPT / VRN;  // this round's stage slots: tid + (h * JN + j) * THREADS
+            if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
+                // (batches of 8 stage reads: with two rounds the other round's values are still in registers)
+                constexpr int VBATCH = VRN == 2 ? 8 : JN;
 #pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                st_stream(vals_out + (((s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + tid + j * THREADS) ^ rev_xor) + rev_add), vv[j]);
-        } else {
+                for (int j0 = J0; j0 < JN; j0 += VBATCH) {
+                    V vv[VBATCH];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const uint32_t i = tid + j * THREADS;
-                uint32_t o = s_gbase[(digs[j >> 2] >> (8 * (j & 3))) & 255u] + i;
-                if (reverse) o = n - 1u - o;
-                GS_ABL_OUT_INDEX(o, i);
-                if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[i]);
+                    for (int j = 0; j < VBATCH; ++j) vv[j] = s_vstage[tid + (j0 + j) * THREADS];
+#pragma unroll
+                    for (int j = 0; j < VBATCH; ++j) {
+                        const int jj = h * JN + j0 + j;
+                        st_stream(vals_out + (((s_gbase[(digs[jj >> 2] >> (8 * (jj & 3))) & 255u] + tid + jj * THREADS) ^ rev_xor) + rev_add), vv[j]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = J0; j < JN; ++j) {
+                    const int jj = h * JN + j;
+                    const uint32_t i = tid + jj * THREADS;
+                    uint32_t o = s_gbase[(digs[jj >> 2] >> (8 * (jj & 3))) & 255u] + i;
+                    if (reverse) o = n - 1u - o;
+                    GS_ABL_OUT_INDEX(o, i);
+                    if (full || (i >= head && i < head + count)) st_stream(vals_out + o, s_vstage[tid + j * THREADS]);
+                }
             }
         }
     }
