@@ -260,7 +260,25 @@ def main():
             sorter.sort(bufs[i], vbufs[i], alt_keys=alt, alt_values=valt)
             return bufs[i], vbufs[i], n
     else:
-        sharded = ShardedOneSweep(n, pairs=pairs, value_bytes=args.pairs or 4)
+        # the product pipeline (C++ over RCCL behind the C-ABI); if ANY rank cannot bring it up, every rank runs the same
+        # steps driven from Python over torch.distributed instead, and the JSON line says so
+        pipeline = "gs_onesweep_sort_sharded (C++ over RCCL)"
+        try:
+            sharded = ShardedOneSweep(n, pairs=pairs, value_bytes=args.pairs or 4)
+            up = 1
+        except Exception as e:  # noqa: BLE001
+            sharded, up = None, 0
+            print(f"rank {rank}: C-ABI multi-GPU pipeline unavailable: {e}", file=sys.stderr)
+        flag = torch.tensor([up], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            from gpusorting_amd.sharded import HipLocalEngine
+            from gpusorting_amd import _lib as _gl
+            if sharded is not None:
+                sharded.close()
+            cap = min(int(n * 1.25) + 256, _gl.GS_MAX_KEYS)
+            sharded = ShardedOneSweep(n, engine=HipLocalEngine(cap, pairs, args.pairs or 4), pairs=pairs, value_bytes=args.pairs or 4)
+            pipeline = "FALLBACK: the same steps driven from Python over torch.distributed (the C-ABI pipeline did not come up on every rank)"
         sorter = sharded.engine.sorter
 
         def step(i):
@@ -312,7 +330,8 @@ def main():
     # bytes exchanged, and the exchange rate per xGMI link against its peak ----
     mgpu = None
     if dist is not None:
-        p = sharded.profile()
+        p = sharded.profile() if sharded._ctx else {"split_ms": 0.0, "exchange_ms": 0.0, "local_sort_ms": 0.0, "total_ms": 0.0,
+                                                    "bytes_sent": 0, "bytes_received": 0}
         mine = torch.tensor([p["split_ms"], p["exchange_ms"], p["local_sort_ms"], p["total_ms"], float(p["bytes_sent"]),
                              float(p["bytes_received"]), float(out_n)], dtype=torch.float64, device=coll_dev)
         allp = [torch.empty_like(mine) for _ in range(world)]
@@ -324,8 +343,7 @@ def main():
         ex_s = mx[1] * 1e-3
         per_rank_gbs = max(sent) / ex_s / 1e9 if ex_s > 0 else 0.0
         mgpu = {
-            "pipeline": "gs_onesweep_sort_sharded (C++ over RCCL): histogram + all-gather + device plan + partition pass | "
-                        "one group of send/recv pairs | local 4-pass OneSweep",
+            "pipeline": pipeline + ": histogram + all-gather + plan + partition pass | bucket exchange | local 4-pass OneSweep",
             "phase_ms_max_over_ranks": {"split": mx[0], "exchange": mx[1], "local_sort": mx[2], "total": mx[3]},
             "phase_ms_rank0": {"split": rows[0][0], "exchange": rows[0][1], "local_sort": rows[0][2], "total": rows[0][3]},
             "bytes_sent_off_rank": {"max": max(sent), "min": min(sent), "sum": sum(sent)},
