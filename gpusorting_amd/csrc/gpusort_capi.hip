@@ -738,7 +738,7 @@ gs_status gs_init_random(void* d_keys, void* d_vals, uint32_t value_bytes, uint3
 
 gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_bytes, uint32_t n, gs_key_type kt,
                       gs_order order, uint32_t* h_err_count, void* stream) {
-    if (!d_keys || !h_err_count || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (!d_keys || !h_err_count || (int)kt < 0 || (int)kt > 5) return GS_ERR_ARG;
     if (n == 0) return GS_ERR_SIZE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint32_t* d_err = nullptr;
@@ -749,7 +749,9 @@ gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_byt
         const uint32_t blocks = div_up(n, 256 * 16) < 2048 ? div_up(n, 256 * 16) : 2048;
         const uint32_t* k = static_cast<const uint32_t*>(d_keys);
         const int desc = order == GS_ORDER_DESCENDING;
-        if (!d_vals || value_bytes == 0)
+        if (is_key64(kt))  // 64-bit keys: the keys' order only
+            hipLaunchKernelGGL(gs::validate64_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint2*>(d_keys), n, (int)kt, desc, d_err);
+        else if (!d_vals || value_bytes == 0)
             hipLaunchKernelGGL(gs::validate_kernel<0>, dim3(blocks), dim3(256), 0, s, k, nullptr, n, (int)kt, desc, d_err);
         else if (value_bytes == 4)
             hipLaunchKernelGGL(gs::validate_kernel<4>, dim3(blocks), dim3(256), 0, s, k, d_vals, n, (int)kt, desc, d_err);

@@ -1829,4 +1829,21 @@ __global__ __launch_bounds__(256) void validate_kernel(const uint32_t* keys, con
     if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(err, bad);
 }
 
+// 64-bit keys: adjacent inversions of the keys only (the payload convention value = key of the 32-bit fixtures has no
+// 64-bit counterpart in the reference)
+__global__ __launch_bounds__(256) void validate64_kernel(const uint2* keys, uint32_t n, int key_type, int descending, uint32_t* err) {
+    auto bits = [&](uint2 k) -> unsigned long long {
+        const uint2 b = key_type == KEY_I64 ? to_bits2<KEY_I64>(k) : key_type == KEY_F64 ? to_bits2<KEY_F64>(k) : k;
+        return ((unsigned long long)b.y << 32) | b.x;
+    };
+    uint32_t bad = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride) {
+        const unsigned long long a = bits(keys[i]), b = bits(keys[i + 1]);
+        bad += descending ? (a < b) : (a > b);
+    }
+    bad = wave_reduce_sum(bad);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(err, bad);
+}
+
 }  // namespace gs

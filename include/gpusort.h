@@ -52,8 +52,8 @@ typedef enum gs_key_type {
     GS_KEY_UINT32 = 0, GS_KEY_INT32 = 1, GS_KEY_FLOAT32 = 2,
     /* 64-bit keys (the reference has 32-bit keys only): 8-byte elements in d_keys / d_alt, sorted in
      * two stable 4-pass rounds (low word, then high word) of the same kernels; values as for 32-bit keys.  Accepted by
-     * gs_onesweep_sort_keys / _sort_pairs / _digit_pass (pass 0..7); not by the histogram read-back, the MSD split
-     * and the fixtures, which are 32-bit. */
+     * gs_onesweep_sort_keys / _sort_pairs / _digit_pass (pass 0..7) and gs_validate; not by the histogram read-back,
+     * the MSD split and the generator, which are 32-bit. */
     GS_KEY_UINT64 = 3, GS_KEY_INT64 = 4, GS_KEY_FLOAT64 = 5
 } gs_key_type;
 /* GPUSortingCUDA/UtilityKernels.cuh:16-24 (value = number of extra AND-ed draws) */
@@ -204,7 +204,7 @@ gs_status gs_init_random(void* d_keys, void* d_vals, uint32_t value_bytes, uint3
 /* Replaces: Validate keys / pairs (UtilityKernels.cuh:402-479) + the 4-byte
  * read-back of DispatchValidateKeys/Pairs (OneSweepDispatcher.cuh:365-391),
  * order/type-aware as GPUSortingD3D12/Shaders/Utility.hlsl:147-230.
- * Synchronous; *h_err_count = number of adjacent inversions. */
+ * Synchronous; *h_err_count = number of adjacent inversions.  64-bit key types: the keys' order only (d_vals ignored). */
 gs_status gs_validate(const void* d_keys, const void* d_vals, uint32_t value_bytes, uint32_t n,
                       gs_key_type key_type, gs_order order, uint32_t* h_err_count, void* stream);
 

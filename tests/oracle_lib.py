@@ -43,6 +43,8 @@ class Oracle:
         lib.gso_std_sort_parallel.restype = None
         lib.gso_sort_permutation_parallel.argtypes = [v, u32, i, i, u32, v]
         lib.gso_sort_permutation_parallel.restype = None
+        lib.gso_key64_to_bits.argtypes = [C.c_uint64, i]
+        lib.gso_key64_to_bits.restype = C.c_uint64
         lib.gso_std_sort64.argtypes = [v, v, u32, u32, i, i]
         lib.gso_std_sort64.restype = None
         lib.gso_digit_binning_pass64.argtypes = [v, v, v, v, u32, u32, u32, i, i]

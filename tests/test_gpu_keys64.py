@@ -44,6 +44,8 @@ def _sort(gpu, keys, kt, order, vals, small_path=True, rank=None):
     s.check()
     r = s.check_state()
     assert (r["rows_not_inclusive"], r["rows_not_monotone"], r["chains_short_of_tickets"], r["hist_words_nonzero"]) == (0, 0, 0, 0), r
+    if keys.size > 1:  # the order-aware Validate, 64-bit form: no inversion after the sort
+        assert gpu.validate(dk, key_type=gpu.KEY_UINT64 + kt, order=order) == 0
     out = dk.cpu().numpy().view(np.uint64), (None if vals is None else dv.cpu().numpy().view(vals.dtype))
     s.close()
     return out
@@ -122,3 +124,15 @@ def test_keys64_2pow24_exact(gpu, oracle):
     np.testing.assert_array_equal(dv.cpu().numpy().view(np.uint32), rv)
     print(f"u64 keys + u32 values, n={n}: {dt * 1e3:.3f} ms (first call)")
     s.close()
+
+
+def test_keys64_validate_counts_inversions(gpu, oracle):
+    """gs_validate on 64-bit keys: the number of adjacent inversions of an unsorted array, per key type and order."""
+    rng = np.random.default_rng(3)
+    n = 100001
+    for kt in (0, 1, 2):
+        keys = _keys(rng, n, "float" if kt == 2 else "uniform")
+        bits = np.array([oracle.lib.gso_key64_to_bits(int(k), kt) for k in keys[:2000]], dtype=np.uint64)
+        part = _dev(np.ascontiguousarray(keys[:2000]))
+        assert gpu.validate(part, key_type=gpu.KEY_UINT64 + kt, order=0) == int(np.count_nonzero(bits[:-1] > bits[1:]))
+        assert gpu.validate(part, key_type=gpu.KEY_UINT64 + kt, order=1) == int(np.count_nonzero(bits[:-1] < bits[1:]))
