@@ -132,7 +132,8 @@ constexpr uint32_t I_CNT_H = PASS_FLAGS + 2;   // this pass gathers counts for t
 constexpr uint32_t I_CNT_START = PASS_FLAGS + 3;   //   first output position of that value's run
 constexpr uint32_t I_CNT_SUBLEN = PASS_FLAGS + 4;  //   keys per position slice
 constexpr uint32_t I_XH = PASS_FLAGS + 5;          // heavy layout: digit group of the heavy value
-constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 6 + 31) / 32) * 32;
+constexpr uint32_t I_MODE = PASS_FLAGS + 6;        // PF_SKEW passes: the most frequent value of this pass's digit
+constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 7 + 31) / 32) * 32;
 constexpr uint32_t PF_SKEW = 1;    // some digit holds >= n/8 keys: rank with wave-aggregated adds
 constexpr uint32_t PF_SKIP = 2;     // every key has the same digit AND the pass is one of an even number of such
                                     // passes: the pass is the identity permutation, its workgroups exit at once
@@ -424,6 +425,9 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                     if (skew_mode & (1u << q)) {
                         // lanes holding the remembered dominant bin are counted with ONE add of their
                         // popcount (by their first lane); all other lanes add individually
+                        // (measured and not kept: counting those lanes on the scalar unit only — a running popcount,
+                        //  added when the guess changes — skewed presets -2 %, uniform +4 %: the cost under skew is the
+                        //  conflicts among the OTHER hot bins, profiles/r02_skew_rank_fixed_mode.txt)
                         uint32_t hit = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -531,6 +535,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     __shared__ uint32_t s_start[MAXCH], s_end[MAXCH], s_rowbase[MAXCH + 1];
     __shared__ uint32_t s_triv;
     __shared__ unsigned long long s_best[2];  // heaviest value of [0] the previous digit (this pass's layout), [1] this digit
+    __shared__ unsigned long long s_mode;     // most frequent value of this digit, if it holds more than 1/8 of the keys
     __shared__ uint32_t s_hv[2][2];           // its run start and count
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
     uint32_t* my_info = info + q * INFO_STRIDE;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
 #pragma unroll
         for (uint32_t x = 0; x < NCH; ++x) hq[x] = q == 0 ? h[0][x] : q == 1 ? h[1][x] : q == 2 ? h[2][x] : h[3][x];
     }
-    if (tid == 0) { s_triv = 0; s_best[0] = 0; s_best[1] = 0; }
+    if (tid == 0) { s_triv = 0; s_best[0] = 0; s_best[1] = 0; s_mode = 0; }
     __syncthreads();
 
     // ---- which passes run (full sorts only).  A pass whose digit is the same for every key is the identity
@@ -577,6 +582,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         if (q >= 1 && gprev > n / GS_HEAVY_SHARE) atomicMax(&s_best[0], ((unsigned long long)gprev << 8) | (255u - tid));
         if (q < 3 && g > n / GS_HEAVY_SHARE) atomicMax(&s_best[1], ((unsigned long long)g << 8) | (255u - tid));
     }
+    if (g >= (n >> 3) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
     // digit scans of this pass's totals and (for the segment starts) of the previous digit's totals
     const uint32_t incl = wave_inclusive_scan(g, lane);
     const uint32_t incl_prev = wave_inclusive_scan(gprev, lane);
@@ -671,6 +677,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         my_info[I_CNT_H] = h_cnt;
         my_info[I_CNT_START] = h_cnt == 0xffffffffu ? 0u : s_hv[1][0];
         my_info[I_CNT_SUBLEN] = h_cnt == 0xffffffffu ? 1u : slice_len(s_hv[1][1]);
+        my_info[I_MODE] = s_mode ? 255u - (uint32_t)(s_mode & 255u) : 0xffffffffu;
     }
 
     // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     // from the upfront histograms no longer bound this pass's writes — do nothing.  Read by another wave, in
     // flight together with the ticket atomic, so it adds no latency.  Same for the pass's flag and plan words.
     if (tid == 64) s_misc[3] = ld_agent(status);
-    if (tid >= 128 && tid < 134) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, cnt_h, cnt_start, cnt_sublen, xh
+    if (tid >= 128 && tid < 135) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, cnt_h, cnt_start, cnt_sublen, xh, mode
     __syncthreads();
     // Everything below that is the same for the whole workgroup is made SCALAR explicitly (values read from LDS
     // or through a VGPR index are vector registers to the compiler: pointers selected by them cost two VGPRs
@@ -1020,50 +1027,38 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
                 }
             }
         } else {
-            // Skewed pass: the lanes holding the wave's remembered dominant digit take ONE add of their
-            // popcount (issued by their first lane) and rank themselves with mbcnt; all other lanes add 1 for
-            // themselves — in the SAME ds_add_rtn instruction (the group contains ALL lanes of that digit, so
-            // group and per-lane adds never meet on one counter inside a round; rounds are ordered by the in-order
-            // LDS queue).  The guess is relearned from the first lane whenever it covers < 8 lanes; that decision
-            // needs ballots only, never a returned value, so the atomics of SKEW_CHUNK rounds are issued back to
-            // back and resolved together (one dependent LDS round trip per chunk instead of two per key).
+            // Skewed pass: the keys holding the pass's MOST FREQUENT digit value (known to scan_kernel from the
+            // histogram: I_MODE, the same for every wave of the pass) never touch the LDS — their rank is the wave's
+            // running count of such keys (a scalar) plus mbcnt of one ballot, and the counter of that digit, which
+            // nobody else adds to, is written once at the end.  All other lanes add 1 for themselves in the same
+            // round.  Nothing depends on a returned value, so the atomics of a chunk are issued back to back.
+            // (The earlier form learned the dominant digit per wave while ranking — ballots, a relearn branch and a
+            // leader election per key: load + rank 6.6 us per 16 384-key tile at entropy preset 3 against 3.3 us now and
+            // 2.4 us for uniform keys, profiles/r02_skew_rank_fixed_mode.txt.)
             constexpr int SKEW_CHUNK = KPT % 8 == 0 ? 8 : 4;
             static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
-            uint32_t sticky = 0xffffffffu;  // wave-uniform
+            const uint32_t sd = uni(s_misc[15]);
+            uint32_t run = 0;  // wave-uniform: keys of digit sd in this wave so far
 #pragma unroll
             for (int c = 0; c < KPT; c += SKEW_CHUNK) {
                 uint32_t ret[SKEW_CHUNK];
-                unsigned long long grp[SKEW_CHUNK];  // wave-uniform: lanes aggregated in round j (0 = none)
 #pragma unroll
                 for (int j = 0; j < SKEW_CHUNK; ++j) {
                     const uint32_t d = (key[c + j] >> shift) & 255u;
-                    unsigned long long m = __builtin_amdgcn_ballot_w64(d == sticky);
-                    if (__popcll(m) < 8) {
-                        sticky = __builtin_amdgcn_readfirstlane(d);
-                        m = __builtin_amdgcn_ballot_w64(d == sticky);
-                        if (__popcll(m) < 8) m = 0;
-                    }
-                    grp[j] = m;
-                    const bool in_grp = m != 0 && d == sticky;
-                    const bool leader = in_grp && __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u;
-                    ret[j] = 0;
-                    if (!in_grp || leader)
-                        ret[j] = __hip_atomic_fetch_add(&whist[d], leader ? (uint32_t)__popcll(m) : 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(d == sd);
+                    ret[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
+                    run += (uint32_t)__popcll(m);
+                    if (d != sd) ret[j] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
 #pragma unroll
                 for (int j = 0; j < SKEW_CHUNK; ++j) {
                     const int i = c + j;
-                    uint32_t r = ret[j];
-                    const unsigned long long m = grp[j];
-                    if (m != 0) {  // uniform
-                        const uint32_t base = __builtin_amdgcn_readlane(ret[j], (uint32_t)__builtin_ctzll(m));
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if ((m >> lane) & 1ull) r = base + below;
-                    }
-                    if (i & 1) offp[i >> 1] |= r << 16; else offp[i >> 1] |= r;
+                    if (i & 1) offp[i >> 1] |= ret[j] << 16; else offp[i >> 1] |= ret[j];
                 }
             }
+            if (lane == 0 && sd < RADIX) whist[sd] = run;
+        }
+        if (pflags & PF_SKEW) {
             // Counting pass (a heavy value implies a skewed pass): next-digit counts of the tile's heavy-value
             // keys.  A loop of its own — inside the ranking loop its non-returning adds made the compiler wait
             // for every ranking atomic (+0.17 ms per pass).  Every thread keeps the count of its own most

@@ -27,7 +27,7 @@ def main():
     s = g.OneSweep(n, mode=g.MODE_PAIRS if vb else g.MODE_KEYS_ONLY, value_bytes=vb)
     vals = None if not vb else torch.empty(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda")
     s.set_shape(t, k)
-    grid = (n + t * k - 1) // (t * k) + 16
+    grid = (n + t * k - 1) // (t * k) + 34  # tiles + MAXCH + 1 (gpusort_capi.hip prologue)
     tr = torch.zeros(4 * grid * 8, dtype=torch.int32, device="cuda")
     lib.gs_debug_set_trace(s._h, tr.data_ptr())
     for rep in range(2):
