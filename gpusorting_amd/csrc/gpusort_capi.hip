@@ -162,8 +162,13 @@ inline bool is_key64(gs_key_type kt) { return (int)kt >= 3; }
 uint32_t hist_blocks(uint32_t n) {
     // one chunk per workgroup at mid sizes (measured: 4/8/16 chunks per workgroup — fewer closing global atomics,
     // less parallelism — are slower: 11 -> 15-23 us at 2^16..2^20)
+    // Up to 2^26 keys fewer workgroups win: every workgroup closes with one global atomic per non-empty bin of its
+    // 4 x 4096-bin LDS histograms (~14 000 of them), which is most of the kernel at these sizes — 512 -> 256 workgroups:
+    // 30 -> 21 us at 2^21, 43 -> 38 us at 2^24, 59 -> 51 us at 2^25 (profiles/r02_hist_blocks_mid_sizes.txt)
     const uint32_t want = div_up(n, gs::HIST_CHUNK);
-    const uint32_t cap = 256 * 2;  // 64 KiB of LDS per workgroup: two per CU
+    const uint32_t cap = n <= (1u << 22) ? 128 : n <= (1u << 26) ? 256 : 256 * 2;  // (80 KiB of LDS per workgroup: at most two per CU)
+    static const int forced = getenv("GPUSORT_HIST_BLOCKS") ? atoi(getenv("GPUSORT_HIST_BLOCKS")) : 0;  // tuning aid
+    if (forced > 0) return (uint32_t)forced < want ? (uint32_t)forced : want;
     return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
