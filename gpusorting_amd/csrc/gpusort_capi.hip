@@ -162,11 +162,18 @@ inline bool is_key64(gs_key_type kt) { return (int)kt >= 3; }
 uint32_t hist_blocks(uint32_t n) {
     // one chunk per workgroup at mid sizes (measured: 4/8/16 chunks per workgroup — fewer closing global atomics,
     // less parallelism — are slower: 11 -> 15-23 us at 2^16..2^20)
-    // Up to 2^26 keys fewer workgroups win: every workgroup closes with one global atomic per non-empty bin of its
-    // 4 x 4096-bin LDS histograms (~14 000 of them), which is most of the kernel at these sizes — 512 -> 256 workgroups:
-    // 30 -> 21 us at 2^21, 43 -> 38 us at 2^24, 59 -> 51 us at 2^25 (profiles/r02_hist_blocks_mid_sizes.txt)
+    // Above that ONE workgroup per CU (half of them up to 2^22 keys): every workgroup closes with one global atomic per
+    // non-empty bin of its 4 x 4096-bin LDS histograms (~14 000 of them) — most of the kernel at mid sizes and still 6 %
+    // of it at 2^28.  512 -> 256 workgroups: 30 -> 21 us at 2^21, 59 -> 51 us at 2^25, 179 -> 156 us at 2^27,
+    // 300 -> 282 us at 2^28; counts that do not divide the CUs evenly (320, 384, 448) lose 10-35 %
+    // (profiles/r02_hist_blocks_mid_sizes.txt).
+    static const uint32_t cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return (uint32_t)v;
+    }();
     const uint32_t want = div_up(n, gs::HIST_CHUNK);
-    const uint32_t cap = n <= (1u << 22) ? 128 : n <= (1u << 26) ? 256 : 256 * 2;  // (80 KiB of LDS per workgroup: at most two per CU)
+    const uint32_t cap = n <= (1u << 22) ? (cus + 1) / 2 : cus;
     static const int forced = getenv("GPUSORT_HIST_BLOCKS") ? atoi(getenv("GPUSORT_HIST_BLOCKS")) : 0;  // tuning aid
     if (forced > 0) return (uint32_t)forced < want ? (uint32_t)forced : want;
     return want < 1 ? 1 : (want > cap ? cap : want);

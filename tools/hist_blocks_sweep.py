@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpusorting_amd as g  # noqa: E402
 
-for lg in (21, 22, 23, 24, 25, 26):
+for lg in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "21,22,23,24,25,26".split(","))]:
     n = 1 << lg
     k = torch.empty(n, dtype=torch.int32, device="cuda")
     s = g.OneSweep(n)
