@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does the relative placement of the four big buffers of a (u32 key, u64 value) sort matter?  The same sort with the
-alt buffers directly behind the inputs (power-of-two spacing) and with them shifted by odd multiples of 4 KiB / 1 MiB."""
+alt buffers directly behind the inputs (power-of-two spacing) and with gaps between them; argv[2] = realloc: a fresh arena per case."""
 import os
 import sys
 
@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gpusorting_amd as g  # noqa: E402
 
 n = 1 << 28
+POOL = None
+REALLOC = len(sys.argv) > 2 and sys.argv[2] == 'realloc'  # a new arena for every case (default: one arena for all)
 vb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 vdt = torch.int64 if vb == 8 else torch.int32
 
@@ -18,8 +20,12 @@ def run(tag, shifts):
     """shifts = extra bytes in front of (alt, vals, valt); the arena is 2 MiB aligned, keys sit at its start"""
     if isinstance(shifts, int):
         shifts = (shifts, shifts, shifts)
-    torch.cuda.empty_cache()
-    pool = torch.empty((4 * n + (n * vb) * 2 + 4 * n + (256 << 20)) // 4 + 16, dtype=torch.int32, device="cuda")  # one arena
+    global POOL
+    if POOL is None or REALLOC:
+        POOL = None
+        torch.cuda.empty_cache()
+        POOL = torch.empty((4 * n + (n * vb) * 2 + 4 * n + (256 << 20)) // 4 + 16, dtype=torch.int32, device="cuda")  # one arena
+    pool = POOL
     base = (pool.data_ptr() + (2 << 20) - 1) & ~((2 << 20) - 1)
     off = base - pool.data_ptr()
 
@@ -46,7 +52,6 @@ def run(tag, shifts):
     print(f"vb={vb} {tag:30s} total={best['total']:.3f} ms passes=[{best['pass0']:.3f} {best['pass1']:.3f} {best['pass2']:.3f} {best['pass3']:.3f}]"
           f"  offsets alt/vals/valt - keys = {[hex((t.data_ptr() - k.data_ptr())) for t in (alt, v, valt) if t is not None]}")
     s.close()
-    del pool
 
 
 K = 1 << 10
