@@ -253,26 +253,42 @@ inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_k
     return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
 }
 
-// mid sizes: two launches (mid_kernels.hpp).  [rank mode][vb index][key type]
-using MidLauncher = void (*)(hipStream_t, uint32_t tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch,
+// mid sizes: two launches (mid_kernels.hpp).  [tile class][rank mode][vb index][key type]; tile classes: 8192 keys
+// (n <= 2^20, every value width), 16 384 (n <= 2^21, keys-only and 4-byte values), 32 768 (n <= 2^22, keys-only)
+using MidLauncher = void (*)(hipStream_t, uint32_t n_tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch,
                              uint32_t* status, uint32_t n, uint32_t descending);
-template <int VB, int KT, int RANK>
+template <int VB, int KT, int RANK, int T, int K>
 void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch, uint32_t* status,
                 uint32_t n, uint32_t descending) {
-    hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK>), dim3(tiles), dim3(gs::MID_THREADS), 0, s, keys, alt, vals, valt, scratch, status, n,
+    hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK, T, K>), dim3(tiles), dim3(T), 0, s, keys, alt, vals, valt, scratch, status, n,
                        descending);
-    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK>), dim3(gs::RADIX), dim3(gs::MID_THREADS), 0, s, keys, alt, vals, valt, scratch, n,
+    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T, K>), dim3(gs::RADIX), dim3(T), 0, s, keys, alt, vals, valt, scratch, n,
                        descending);
 }
-#define GS_MID_ROW(VB, R) {launch_mid<VB, 0, R>, launch_mid<VB, 1, R>, launch_mid<VB, 2, R>}
-const MidLauncher g_mid[2][3][3] = {{GS_MID_ROW(0, 0), GS_MID_ROW(4, 0), GS_MID_ROW(8, 0)}, {GS_MID_ROW(0, 1), GS_MID_ROW(4, 1), GS_MID_ROW(8, 1)}};
+#define GS_MID_ROW(VB, R, T, K) {launch_mid<VB, 0, R, T, K>, launch_mid<VB, 1, R, T, K>, launch_mid<VB, 2, R, T, K>}
+#define GS_MID_NONE {nullptr, nullptr, nullptr}
+const MidLauncher g_mid[3][2][3][3] = {
+    {{GS_MID_ROW(0, 0, 512, 16), GS_MID_ROW(4, 0, 512, 16), GS_MID_ROW(8, 0, 512, 16)},
+     {GS_MID_ROW(0, 1, 512, 16), GS_MID_ROW(4, 1, 512, 16), GS_MID_ROW(8, 1, 512, 16)}},
+    {{GS_MID_ROW(0, 0, 512, 32), GS_MID_ROW(4, 0, 512, 32), GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32), GS_MID_ROW(4, 1, 512, 32), GS_MID_NONE}},
+    {{GS_MID_ROW(0, 0, 1024, 32), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 1024, 32), GS_MID_NONE, GS_MID_NONE}},
+};
+constexpr uint32_t g_mid_tile[3] = {512 * 16, 512 * 32, 1024 * 32};
+// tile class of a mid-size sort, -1: the general pipeline
+inline int mid_class(uint32_t n, uint32_t vb) {
+    if (n <= gs::MID_MAX_TILES * g_mid_tile[0]) return 0;
+    if (n <= gs::MID_MAX_TILES * g_mid_tile[1] && vb != 8) return 1;
+    if (n <= gs::MID_MAX_TILES * g_mid_tile[2] && vb == 0) return 2;
+    return -1;
+}
 
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
-    // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20; the general
-    // pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
+    // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20 (2^21 for keys-only and
+    // 4-byte values, 2^22 for keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
     // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
-    const bool use_mid = h->mid_path && h->shape_auto && n > gs::SMALL_TILE && n <= gs::MID_MAX_KEYS && !is_key64(kt);
+    const int mid_cls = (h->mid_path && h->shape_auto && n > gs::SMALL_TILE && !is_key64(kt)) ? mid_class(n, vb) : -1;
+    const bool use_mid = mid_cls >= 0;
     if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
@@ -288,7 +304,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     if (use_mid) {
         // one MSD pass + one LDS sort per top-byte bucket (a skewed top byte: the LSD passes inside the first kernel)
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
-        g_mid[h->rank_mode][vb_index(vb)][kt](s, div_up(n, gs::MID_TILE), static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys),
+        g_mid[mid_cls][h->rank_mode][vb_index(vb)][kt](s, div_up(n, g_mid_tile[mid_cls]), static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys),
                                               d_vals, d_alt_vals, h->slab + gs::SLAB_MID, h->slab + SLAB_STATUS, n,
                                               order == GS_ORDER_DESCENDING ? 1u : 0u);
         h->last_tile = 0;

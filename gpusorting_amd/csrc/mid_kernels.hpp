@@ -1,10 +1,12 @@
-// mid_kernels.hpp — the TWO-launch sort of mid-size inputs (single-tile limit < n <= MID_MAX_KEYS = 2^20).
+// mid_kernels.hpp — the TWO-launch sort of mid-size inputs (single-tile limit < n <= 2^20; keys-only and 4-byte
+// values up to 2^21, keys-only up to 2^22, with larger tiles).
 //
 // SURVEY.md 8f N1 / the reference's BenchmarkOneSweep size sweep (GPUSortingD3D12/Tests.h:392-393,415-416): between
 // 2^14 and 2^20 keys the six-launch pipeline is a ~50 us plateau of launch and tile latencies (profiles/
 // r01_size_and_entropy_sweep_v3.txt) — four global passes of >= 9 us each whatever the size.  At these sizes the keys
 // of one top-byte value fit ONE workgroup's LDS, so the sort is done as
-//   K1 mid_msd_kernel     one MSD pass: every workgroup (one 8192-key tile each, at most 128, all resident) ranks its
+//   K1 mid_msd_kernel     one MSD pass: every workgroup (one tile each — 8192 keys, 16 384 above 2^20, 32 768 above 2^21 —
+//                         at most 128, all resident) ranks its
 //                         tile by the TOP byte, publishes its 256 counts, meets the others at ONE grid barrier, derives
 //                         every bucket's start and its own offsets from the count table, and scatters its tile into the
 //                         alt buffer (stable);
@@ -23,10 +25,13 @@
 
 namespace gs {
 
-constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // 8192 keys per workgroup
-constexpr uint32_t MID_MAX_KEYS = 1u << 20;                                            // <= 128 tiles
-constexpr uint32_t MID_MAX_TILES = MID_MAX_KEYS / MID_TILE;
-constexpr uint32_t MID_BUCKET_CAP = MID_TILE;       // keys of one top-byte value K2 sorts in LDS
+// Three tile shapes, always at most 128 tiles; a top-byte bucket must fit ONE tile (K2 sorts it in LDS):
+//   512 x 16 =  8 192 keys  n <= 2^20   every value width
+//   512 x 32 = 16 384 keys  n <= 2^21   keys-only and 4-byte values (stage 64 + 64 KiB)
+//  1024 x 32 = 32 768 keys  n <= 2^22   keys-only (stage 128 KiB)
+constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // the smallest shape
+constexpr uint32_t MID_MAX_TILES = 128;
+constexpr uint32_t MID_MAX_KEYS = MID_MAX_TILES * MID_TILE;                            // 2^20: limit of the smallest shape
 // scratch words in the handle's slab (SLAB_MID: its own region, zero whenever no mid-size sort is in flight)
 constexpr uint32_t MID_ARRIVE = 0;                  // barrier counter: counts up during K1, K2 puts it back to zero
 constexpr uint32_t MID_ROUTE = 32;                  // 0 = MSD route (K2 sorts the buckets), 1 = K1 did the LSD passes
@@ -51,12 +56,14 @@ struct SC1T { using type = uint32_t; };
 template <>
 struct SC1T<8> { using type = unsigned long long; };
 
-// Rank the tile's keys among the keys of their digit inside their wave (see digit_binning_kernel): off[i] = rank,
-// the per-wave counters keep the counts.  RANK 1: slots >= count take no part; RANK 0 (ballots): the all-ones dummy
+// Rank the tile's keys among the keys of their digit inside their wave (see digit_binning_kernel): off = the ranks (below
+// 64 * KPT <= 2048: two per register, which keeps the 32-keys-per-thread shapes out of scratch), the per-wave counters keep the counts.  RANK 1: slots >= count take no part; RANK 0 (ballots): the all-ones dummy
 // keys behind `count` rank last in digit 255.
 template <int RANK, int KPT>
 __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t shift, uint32_t my_base, uint32_t count,
-                                         uint32_t* whist, uint32_t (&off)[KPT]) {
+                                         uint32_t* whist, uint32_t (&off)[KPT / 2]) {
+#pragma unroll
+    for (int i = 0; i < KPT / 2; ++i) off[i] = 0;
     if constexpr (RANK == 0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
@@ -75,15 +82,14 @@ __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t sh
             const uint32_t pre = whist[d];
             if (below == total - 1u) whist[d] = pre + total;
             asm volatile("" ::: "memory");
-            off[i] = pre + below;
+            off[i >> 1] |= (pre + below) << (16 * (i & 1));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
-            off[i] = 0;
             if (my_base + i * 64u < count)
-                off[i] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                off[i >> 1] |= __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << (16 * (i & 1));
         }
     }
 }
@@ -112,13 +118,13 @@ __device__ __forceinline__ bool mid_barrier(uint32_t* arrive, uint32_t target, u
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
-template <int VB, int KT, int RANK>
-__global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, uint32_t* alt, void* vals_, void* valt_, uint32_t* scratch,
-                                                              uint32_t* status, uint32_t n, uint32_t descending) {
+template <int VB, int KT, int RANK, int THREADS_ = (int)MID_THREADS, int KPT_ = (int)MID_KPT>
+__global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint32_t* alt, void* vals_, void* valt_, uint32_t* scratch,
+                                                           uint32_t* status, uint32_t n, uint32_t descending) {
     using V = typename ValT<VB>::type;
     using VA = typename SC1T<VB>::type;
-    constexpr int KPT = MID_KPT, WAVES = MID_THREADS / 64;
-    constexpr uint32_t THREADS = MID_THREADS, TILE = MID_TILE;
+    constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
+    constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, ui
     // One partition step of the tile on the digit at `shift`: rank, tile counts -> table row, grid barrier, bases from
     // the table (digit starts + the tiles in front), stage.  Leaves s_gbase[d] = global position of stage slot 0 of
     // digit d's run minus its stage offset, and G (all tiles' count of this thread's digit) in the return value.
-    uint32_t off[KPT];
+    uint32_t off[KPT / 2];
     auto partition_step = [&](uint32_t shift, uint32_t* table, bool& alive) -> uint32_t {
         for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
         if (tid == 0) s_max = 0;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, ui
     auto stage = [&](uint32_t shift) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
+            const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
             if (RANK == 0 || my_base + i * 64u < count) {
                 s_stage[lpos] = key[i];
                 if constexpr (VB != 0) s_vstage[lpos] = val[i];
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, ui
     uint32_t* table1 = table0 + MID_MAX_TILES * RADIX;
     const uint32_t G = partition_step(24, table0, alive);
     if (!alive) return;
-    const bool lsd_route = s_max > MID_BUCKET_CAP;  // the same table everywhere: the same decision everywhere
+    const bool lsd_route = s_max > TILE;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
     __syncthreads();  // everybody has read s_max before the next partition step resets it
     if (tile == 0 && tid < RADIX) {
         scratch[MID_BSTART + tid] = s_gbase[tid] + s_dpre[tid];  // tile 0 has no tile in front: its base IS the digit start
@@ -291,12 +297,12 @@ __global__ __launch_bounds__(MID_THREADS) void mid_msd_kernel(uint32_t* keys, ui
 // ---------------------------------------------------------------------------
 // K2: one workgroup per top-byte bucket; the low 24 bits in three stable LDS passes
 // ---------------------------------------------------------------------------
-template <int VB, int KT, int RANK>
-__global__ __launch_bounds__(MID_THREADS) void bucket_sort_kernel(uint32_t* keys, const uint32_t* alt, void* vals_, const void* valt_,
-                                                                  uint32_t* scratch, uint32_t n, uint32_t descending) {
+template <int VB, int KT, int RANK, int THREADS_ = (int)MID_THREADS, int KPT_ = (int)MID_KPT>
+__global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, const uint32_t* alt, void* vals_, const void* valt_,
+                                                               uint32_t* scratch, uint32_t n, uint32_t descending) {
     using V = typename ValT<VB>::type;
-    constexpr int KPT = MID_KPT, WAVES = MID_THREADS / 64;
-    constexpr uint32_t THREADS = MID_THREADS, TILE = MID_TILE;
+    constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
+    constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(MID_THREADS) void bucket_sort_kernel(uint32_t* keys
     for (uint32_t shift = 0; shift < 24; shift += 8) {
         for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
         __syncthreads();
-        uint32_t off[KPT];
+        uint32_t off[KPT / 2];
         mid_rank<RANK, KPT>(key, shift, my_base, count, whist, off);
         __syncthreads();
         uint32_t run = 0, scan_incl = 0;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(MID_THREADS) void bucket_sort_kernel(uint32_t* keys
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const uint32_t lpos = off[i] + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
+            const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
             if (RANK == 0 || my_base + i * 64u < count) {
                 s_stage[lpos] = key[i];
                 if constexpr (VB != 0) s_vstage[lpos] = val[i];

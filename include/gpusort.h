@@ -128,9 +128,10 @@ gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
  * mode, n <= 16384 for keys-only and 4-byte values, n <= 32768 for keys-only — unless this is switched off
  * (tests use 0 to push small sizes through the tiled path as well). */
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
-/* Mid sizes (single-tile limit < n <= 2^20, 32-bit keys) are sorted in TWO launches instead of six: one MSD pass on the
+/* Mid sizes (single-tile limit < n <= 2^20; keys-only and 4-byte values up to 2^21, keys-only up to 2^22; 32-bit keys) are
+ * sorted in TWO launches instead of six: one MSD pass on the
  * top byte (all workgroups resident, one grid barrier) and one workgroup per top-byte bucket that sorts the remaining 24
- * bits in LDS; a top byte too skewed for that (a bucket above 8192 keys) is noticed on the device and the first kernel
+ * bits in LDS; a top byte too skewed for that (a bucket above one tile: 8192 / 16 384 / 32 768 keys) is noticed on the device and the first kernel
  * runs the four LSD passes itself (reference size sweep GPUSortingD3D12/Tests.h:392-393,415-416).  Same
  * result either way; 0 sends these sizes through the general path.  Only used while the library picks the tile shape.
  * Default 1; env GPUSORT_MID_PATH=0/1 sets it at create. */

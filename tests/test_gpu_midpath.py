@@ -1,4 +1,4 @@
-"""The two-launch sort of mid-size inputs (single-tile limit < n <= 2^20; gpusorting_amd/csrc/mid_kernels.hpp):
+"""The two-launch sort of mid-size inputs (single-tile limit < n <= 2^20, keys-only up to 2^22; gpusorting_amd/csrc/mid_kernels.hpp):
 one MSD pass on the top byte + one LDS sort per top-byte bucket, and — when a bucket would not fit a workgroup — the
 four LSD passes inside the first kernel.  SURVEY.md §8f N1; the reference's size sweep is
 GPUSortingD3D12/Tests.h:392-393,415-416 and Unity's ladder GPUSortingUnity/Tests/TestBase.cs:238-264.  Every case
@@ -72,6 +72,49 @@ def test_mid_path_types_orders_rank_modes(gpu, oracle, kt, order, rank):
         rk, rv = oracle.std_sort(keys, kt, order, vals)
         np.testing.assert_array_equal(ok, rk, err_msg=f"{kind} n={n} kt={kt} order={order} rank={rank}")
         np.testing.assert_array_equal(ov, rv, err_msg=f"{kind} values n={n} kt={kt} order={order} rank={rank}")
+        s.close()
+
+
+# the larger tile classes: 16 384-key tiles up to 2^21 keys (keys-only, 4-byte values), 32 768-key tiles up to 2^22 (keys-only);
+# 8-byte values leave the two-launch route at 2^20 + 1 keys, 4-byte values at 2^21 + 1 (general pipeline: still exact)
+BIG_SIZES = ((1 << 20) + 1, (1 << 20) + 12345, (1 << 21) - 7, 1 << 21, (1 << 21) + 1, 3000001, 1 << 22)
+
+
+@pytest.mark.parametrize("vb", [0, 4, 8])
+@pytest.mark.parametrize("kind", ["uniform", "preset4", "top-constant"])
+def test_mid_path_larger_tile_classes(gpu, oracle, vb, kind):
+    rng = np.random.default_rng(23 + vb)
+    for n in BIG_SIZES:
+        if vb == 8 and n > (1 << 21):
+            continue
+        keys = _keys(oracle, rng, n, kind)
+        vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+        ref = oracle.std_sort(keys, 0, 0, vals)
+        rk, rv = (ref, None) if vals is None else ref
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb)
+        for mid in (True, False):
+            s.set_mid_path(mid)
+            ok, ov = _sort(gpu, s, keys, vals)
+            np.testing.assert_array_equal(ok, rk, err_msg=f"{kind} n={n} vb={vb} mid={mid}")
+            if vb:
+                np.testing.assert_array_equal(ov, rv, err_msg=f"{kind} values n={n} vb={vb} mid={mid}")
+        s.close()
+
+
+@pytest.mark.parametrize("kt,order,rank", [(1, 1, 1), (2, 0, 0), (2, 1, 1), (0, 1, 0)])
+def test_mid_path_larger_tile_classes_types(gpu, oracle, kt, order, rank):
+    rng = np.random.default_rng(31)
+    for n, vb in (((1 << 21) - 1, 4), ((1 << 22) - 3, 0)):
+        keys = _keys(oracle, rng, n, "uniform")
+        vals = None if not vb else np.arange(n, dtype=np.uint32)
+        s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
+        s.set_rank_mode(rank)
+        ok, ov = _sort(gpu, s, keys, vals)
+        ref = oracle.std_sort(keys, kt, order, vals)
+        rk, rv = (ref, None) if vals is None else ref
+        np.testing.assert_array_equal(ok, rk, err_msg=f"n={n} kt={kt} order={order} rank={rank}")
+        if vb:
+            np.testing.assert_array_equal(ov, rv, err_msg=f"values n={n} kt={kt} order={order} rank={rank}")
         s.close()
 
 
