@@ -108,9 +108,10 @@ using gs::SLAB_STATUS;
 
 constexpr uint32_t MIN_TILE = 4096;  // smallest tile of any compiled shape (sizing of the slab)
 constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb) unless the caller picked a shape
-// profiles/r01_mid_sweep_shapes.txt: 512x16 wins up to 2^23 keys for keys-only sorts (-20 % at 2^14..2^18), up to 2^24
-// with 4-byte values and up to 2^25 with 8-byte values (whose big tile leaves one workgroup per CU)
-inline uint32_t mid_keys(uint32_t vb) { return vb == 8 ? (1u << 25) : vb == 4 ? (1u << 24) : (1u << 23); }
+// profiles/r02_shape_by_size.txt (general path, back-to-back sorts): the 8192-key tile wins up to 2^25 keys for keys-only
+// sorts (180 vs 194 us at 2^24, 293 vs 302 at 2^25, loses at 2^26) and for 8-byte values (whose big tile leaves one
+// workgroup per CU), up to 2^23 with 4-byte values (1024 x 16 wins from 2^24)
+inline uint32_t mid_keys(uint32_t vb) { return vb == 4 ? (1u << 23) : (1u << 25); }
 
 }  // namespace
 
