@@ -42,6 +42,7 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
             v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
             ref = torch.sort(k.to(torch.int64) & 0xffffffff, stable=True)
             s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+            s.set_mid_path(False)          # 2^22 keys-only would take the two-launch route: no descriptors, nothing withheld
             t0 = time.time()
             s.sort(k, v)
             s.check()                      # raises on GS_ERR_TIMEOUT
@@ -59,10 +60,11 @@ def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
         import sys, time, torch
         sys.path.insert(0, %r)
         import gpusorting_amd as g
-        n = 1 << 22                       # 256 tiles, 16 per chain: tile 5 of chain 3 stays silent in every pass
+        n = 1 << 22                       # 512 tiles of 8192 keys, 32 per chain: tile 5 of chain 3 stays silent in every pass
         k = torch.empty(n, dtype=torch.int32, device="cuda")
         g.init_random(k, 10, 0)
         s = g.OneSweep(n)
+        s.set_mid_path(False)             # the general pipeline (this size would take the two-launch route)
         t0 = time.time()
         s.sort(k)
         try:
