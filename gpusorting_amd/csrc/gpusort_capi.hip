@@ -50,8 +50,12 @@ void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* 
 }
 // the two-round form of the 8-byte-value pass (two workgroups per CU), launched beside the one-round form in full
 // sorts; the pass's PF_SKEW flag decides on the device which of the two works.  [rank mode][key type]
+#ifdef GS_MINIMAL  // experiment builds (tools/): u32 keys-only kernels of the three product shapes, nothing else — a 10 s compile
+const BinLauncher g_vr2[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+#else
 const BinLauncher g_vr2[2][3] = {{launch_bin<512, 32, 8, 0, 0, 2>, launch_bin<512, 32, 8, 1, 0, 2>, launch_bin<512, 32, 8, 2, 0, 2>},
                                  {launch_bin<512, 32, 8, 0, 1, 2>, launch_bin<512, 32, 8, 1, 1, 2>, launch_bin<512, 32, 8, 2, 1, 2>}};
+#endif
 
 struct Shape {
     int threads, kpt;
@@ -85,6 +89,11 @@ struct Shape {
 #define GS_FULL(T, K) {T, K, {GS_ROWS(T, K, 0), GS_ROWS(T, K, 1)}}
 #define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}}
 
+#ifdef GS_MINIMAL
+#define GS_ROWS_KEYS64(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}}
+#define GS_KEYSONLY64(T, K) {T, K, {GS_ROWS_KEYS64(T, K, 0), GS_ROWS_KEYS64(T, K, 1)}}
+const Shape g_shapes[] = {GS_KEYSONLY64(512, 32), GS_KEYSONLY64(1024, 16), GS_KEYSONLY64(512, 16)};
+#else
 const Shape g_shapes[] = {
     GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
     GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
@@ -95,6 +104,7 @@ const Shape g_shapes[] = {
     GS_U32ONLY(512, 20),  // 10 240-key tiles: 52 KiB of LDS, three workgroups per CU
 #endif
 };
+#endif
 constexpr int g_num_shapes = sizeof(g_shapes) / sizeof(g_shapes[0]);
 
 inline int vb_index(uint32_t vb) { return vb == 0 ? 0 : vb == 4 ? 1 : 2; }
@@ -141,6 +151,7 @@ struct gs_onesweep {
     // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
     uint32_t last_n, last_tile, last_p0, last_np, last_dyn, last_desc_stride;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
+    bool exp_keep_desc;  // experiment builds (GS_EXP & 1024): the histogram kernel leaves the descriptor rows alone
 };
 
 namespace {
@@ -195,7 +206,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const uint32_t tiles = div_up(n, tile);
     const uint32_t rows = tiles + 2 * gs::MAXCH + 2;  // every chain: its tiles (+1 partial) + row 0
     const uint32_t desc_stride = rows * gs::RADIX;
-    const size_t used_words = SLAB_DESC + (size_t)np * desc_stride;
+    const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
     // position segments of the first pass: equal, multiples of the histogram chunk
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
     // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
@@ -241,6 +252,7 @@ void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_
      launch_small<T, K, VB, 4, R>, launch_small<T, K, VB, 5, R>}
 #define GS_SMALL_NONE {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 // [size class][rank mode][vb index][key type]; 64-bit keys: the 8192-slot class only
+#ifndef GS_MINIMAL
 const SmallLauncher g_small[3][2][3][6] = {
     {{GS_SMALL_ROW64(512, 16, 0, 0), GS_SMALL_ROW64(512, 16, 4, 0), GS_SMALL_ROW64(512, 16, 8, 0)},
      {GS_SMALL_ROW64(512, 16, 0, 1), GS_SMALL_ROW64(512, 16, 4, 1), GS_SMALL_ROW64(512, 16, 8, 1)}},
@@ -249,9 +261,14 @@ const SmallLauncher g_small[3][2][3][6] = {
     {{GS_SMALL_ROW(1024, 32, 0, 0), GS_SMALL_NONE, GS_SMALL_NONE},
      {GS_SMALL_ROW(1024, 32, 0, 1), GS_SMALL_NONE, GS_SMALL_NONE}},
 };
+#endif
 inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_key_type kt) {
+#ifdef GS_MINIMAL
+    return nullptr;
+#else
     const int cls = n <= 8192 ? 0 : n <= 16384 ? 1 : n <= 32768 ? 2 : 3;
     return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
+#endif
 }
 
 // mid sizes: two launches (mid_kernels.hpp).  [tile class][rank mode][vb index][key type]; tile classes: 8192 keys
@@ -266,6 +283,7 @@ void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, vo
     hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T, K>), dim3(gs::RADIX), dim3(T), 0, s, keys, alt, vals, valt, scratch, n,
                        descending);
 }
+#ifndef GS_MINIMAL
 #define GS_MID_ROW(VB, R, T, K) {launch_mid<VB, 0, R, T, K>, launch_mid<VB, 1, R, T, K>, launch_mid<VB, 2, R, T, K>}
 #define GS_MID_NONE {nullptr, nullptr, nullptr}
 const MidLauncher g_mid[3][2][3][3] = {
@@ -274,6 +292,7 @@ const MidLauncher g_mid[3][2][3][3] = {
     {{GS_MID_ROW(0, 0, 512, 32), GS_MID_ROW(4, 0, 512, 32), GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32), GS_MID_ROW(4, 1, 512, 32), GS_MID_NONE}},
     {{GS_MID_ROW(0, 0, 1024, 32), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 1024, 32), GS_MID_NONE, GS_MID_NONE}},
 };
+#endif
 constexpr uint32_t g_mid_tile[3] = {512 * 16, 512 * 32, 1024 * 32};
 // tile class of a mid-size sort, -1: the general pipeline
 inline int mid_class(uint32_t n, uint32_t vb) {
@@ -289,7 +308,11 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // 4-byte values, 2^22 for keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
     // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
     const int mid_cls = (h->mid_path && h->shape_auto && n > gs::SMALL_TILE && !is_key64(kt)) ? mid_class(n, vb) : -1;
+#ifdef GS_MINIMAL
+    const bool use_mid = false;
+#else
     const bool use_mid = mid_cls >= 0;
+#endif
     if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
@@ -302,6 +325,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         // the single-tile kernel has no spin and cannot time out
         return GS_OK;
     }
+#ifndef GS_MINIMAL
     if (use_mid) {
         // one MSD pass + one LDS sort per top-byte bucket (a skewed top byte: the LSD passes inside the first kernel)
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
@@ -315,6 +339,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         h->profile_pending = h->profiling != 0;
         return GS_OK;
     }
+#endif
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
     int shape = (h->shape_auto && n <= mid_keys(vb)) ? MID_SHAPE : h->shape;
     if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
@@ -335,6 +360,12 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // Each round leaves its result in the caller's buffers (an even number of passes runs, or identity passes are
     // dropped in pairs), and only the last round carries the descending reversal.
     const uint32_t rounds = is_key64(kt) ? 2u : 1u;
+#if (GS_EXP & 1024)
+    const uint32_t exp_mode = getenv("GPUSORT_EXPMODE") ? (uint32_t)atoi(getenv("GPUSORT_EXPMODE")) & (256u | 512u | 1024u) : 0u;
+    h->exp_keep_desc = (exp_mode & 256u) != 0u;
+#else
+    const uint32_t exp_mode = 0u;
+#endif
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
@@ -348,7 +379,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
             fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
-               mode | (two_forms ? 32u : 0u));
+               mode | (two_forms ? 32u : 0u) | exp_mode);
             if (two_forms)
                 g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                         h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
@@ -454,6 +485,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->msd_keys = nullptr;
     h->last_n = h->last_tile = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
     h->hist_dirty = false;
+    h->exp_keep_desc = false;
     h->msd_n = h->msd_grid = 0;
     h->msd_kt = GS_KEY_UINT32;
     h->slab_words = slab_words_for(max_keys);
@@ -602,6 +634,17 @@ gs_status gs_onesweep_check(gs_onesweep* h, void* stream) {
     GS_HIP(hipStreamSynchronize(s));
     return h->pinned[0] == gs::STATUS_OK ? GS_OK : GS_ERR_TIMEOUT;
 }
+
+#if (GS_EXP & 1024)
+gs_status gs_debug_read_status_words(gs_onesweep* h, uint32_t out[32], void* stream) {  // experiment builds only
+    if (!h || !out) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_STATUS, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    memcpy(out, h->pinned, 32 * sizeof(uint32_t));
+    return GS_OK;
+}
+#endif
 
 gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream) {
     if (!h || !report) return GS_ERR_ARG;
@@ -822,7 +865,7 @@ gs_status gs_msd_splitters(const uint64_t hist256[256], uint32_t world, uint32_t
 // own GlobalHistogram kernel counts for the last pass (chain = group of the previous digit), bin = d3*16 + (d2>>4).
 gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt,
                                          uint32_t* h_hist4096, void* stream) {
-    static_assert(gs::NCH == 16, "the fine MSD histogram is the 16-chain joint histogram");
+    if (gs::NCH != 16) return GS_ERR_ARG;  // the fine MSD histogram is the 16-chain joint histogram (tuning builds with other chain counts)
     if (!h || !d_keys || !h_hist4096 || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
     if (n == 0 || n > h->max_keys || n > GS_MAX_KEYS) return GS_ERR_SIZE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -833,6 +876,9 @@ gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uin
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
     h->hist_dirty = false;
+    if (h->profiling)  // slots 0..2 (clear, histogram, scan) are this call's; the pass slots read 0
+        for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
+    h->profile_pending = h->profiling != 0;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t d = 0; d < gs::RADIX; ++d)
         for (uint32_t x = 0; x < gs::NCH; ++x) h_hist4096[d * gs::NCH + x] = h->pinned[gs::hist_index(1, d, x)];

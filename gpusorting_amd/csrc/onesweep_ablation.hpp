@@ -41,7 +41,22 @@
 #define GS_ABL_NO_HEAVY_FLUSH (((GS_EXP)&32) != 0)
 #define GS_ABL_NO_HEAVY_LAYOUT (((GS_EXP)&64) != 0)
 #define GS_ABL_LOOKBACK_SKIPPED (((GS_EXP)&1) != 0)
-#define GS_ABL_GENERIC_SCATTER (((GS_EXP)&257) != 0)
+#define GS_ABL_GENERIC_SCATTER (((GS_EXP)&(257 | 1024)) != 0)
+// 1024: the look-back / scatter decomposition of round 3 (tools/r03_ablate.py); the variants are RUNTIME bits of the
+//       kernel's mode word (GPUSORT_EXPMODE, read by the host at every sort), so one build serves every combination:
+//         mode 256   replay: the descriptors of an identical earlier sort are still in the slab (the histogram kernel
+//                    does not clear them) and no tile publishes REDUCTION, so every look-back finds its predecessor's
+//                    INCLUSIVE row in its first read — a look-back of exactly one round trip, exact positions
+//         mode 512   the predecessor's row is requested before the key loads and consumed in the look-back (with 256:
+//                    a look-back that never waits)
+//         mode 1024  sequential output positions (the real look-back still runs)
+#define GS_ABL_REPLAY (((GS_EXP)&1024) && (mode & 256u))
+#define GS_ABL_EARLY_ROW(v) do { if (((GS_EXP)&1024) && (mode & 512u) && tid < RADIX) (v) = ld_agent(&cdesc[(size_t)tile * RADIX + tid]); } while (0)
+#define GS_ABL_EARLY_USE(v) do { if (((GS_EXP)&1024) && (mode & 512u) && !finished && ((v) & FLAG_MASK) == FLAG_INCLUSIVE) { prev = (v) >> 2; done = true; } } while (0)
+#define GS_ABL_CLOCKS_BEGIN() const unsigned long long abl_c0_ = (unsigned long long)clock64(), abl_w0_ = (unsigned long long)wall_clock64()
+#define GS_ABL_CLOCKS_END() do { if (((GS_EXP)&1024) && blockIdx.x == 0 && threadIdx.x == 0) { \
+        unsigned long long* c_ = reinterpret_cast<unsigned long long*>(slab + SLAB_STATUS + 16); \
+        c_[0] = abl_c0_; c_[1] = abl_w0_; c_[2] = (unsigned long long)clock64(); c_[3] = (unsigned long long)wall_clock64(); } } while (0)
 #if (GS_EXP & 256)
 #define GS_ABL_ASSUME_PREV() do { if (!finished) { prev = (ld_agent(&cdesc[tid]) >> 2) + tile * tile_total; done = true; } } while (0)
 #else
@@ -52,4 +67,5 @@
     do {                                                           \
         if ((GS_EXP)&1) (o) = (tile_base + (i)) % n;               \
         if ((GS_EXP)&256) (o) = (o) % n;                           \
+        if (((GS_EXP)&1024) && (mode & 1024u)) (o) = tile_base + (i); \
     } while (0)

@@ -80,6 +80,11 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #define GS_ABL_ASSUME_PREV() do { } while (0)  // no wait, positions extrapolated from this tile's own counts
 #define GS_ABL_GENERIC_SCATTER false           // force the generic (masked) scatter loops
 #define GS_ABL_OUT_INDEX(o, i) do { } while (0)  // rewrite an output index (sequential / wrapped)
+#define GS_ABL_REPLAY false                    // descriptors of an identical earlier run are still there: no REDUCTION publish
+#define GS_ABL_EARLY_ROW(v) do { } while (0)   // request the predecessor's row before the key loads
+#define GS_ABL_EARLY_USE(v) do { } while (0)   // ... and take it in the look-back if it is INCLUSIVE
+#define GS_ABL_CLOCKS_BEGIN() do { } while (0)  // histogram kernel: shader clock against the 100 MHz wall clock
+#define GS_ABL_CLOCKS_END() do { } while (0)
 #endif
 // (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
 //  returns a not-yet-final row and the wait moves in front of staging)
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t* hist = slab + SLAB_HIST;
+    GS_ABL_CLOCKS_BEGIN();
     // This kernel is also the sort's CLEAR (reference: ClearMemory, OneSweepDispatcher.cuh:301-309): it zeroes the
     // scan state nobody reads before it ends — ticket counters, status, info, slice counts, descriptors — as
     // 16-byte grid-stride stores next to its read stream; a separate memset was one more launch (5 us of a 50 us
@@ -515,6 +521,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         const uint32_t v = s_h[i];
         if (v) atomicAdd(&hist[i], v);
     }
+    GS_ABL_CLOCKS_END();
 }
 
 // ---------------------------------------------------------------------------
@@ -908,6 +915,8 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
         st_agent(&cdesc[tid], (seed << 2) | FLAG_INCLUSIVE);
     }
     GS_TRACE(1);
+    uint32_t early_row = 0;
+    GS_ABL_EARLY_ROW(early_row);
 
     // ---- load (wave-striped, coalesced 256 B per wave-instruction; 64-bit keys: 512 B) ----
     uint32_t key[KPT];
@@ -1106,7 +1115,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
         // same numbers a fallback recount of this tile produces
         dummies = (tid == 0 ? head : 0u) + ((tid == RADIX - 1 && !full && !tail_unranked) ? TILE - head - count : 0u);
         tile_total = run - dummies;
-        if (!GS_FAULT_TILE(chain, tile))
+        if (!GS_FAULT_TILE(chain, tile) && !GS_ABL_REPLAY)
             st_agent(&cdesc[(size_t)(tile + 1u) * RADIX + tid], (tile_total << 2) | FLAG_REDUCTION);
         scan_incl = wave_inclusive_scan_dpp(run);
         if (lane == 63) s_misc[4 + wave] = scan_incl;
@@ -1216,6 +1225,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     };
     GS_TRACE(4);
     GS_ABL_ASSUME_PREV();
+    GS_ABL_EARLY_USE(early_row);
     for (;;) {
         if (!finished) {
             walk(IntTag<GS_WALK_ROWS>{});
