@@ -360,8 +360,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // Each round leaves its result in the caller's buffers (an even number of passes runs, or identity passes are
     // dropped in pairs), and only the last round carries the descending reversal.
     const uint32_t rounds = is_key64(kt) ? 2u : 1u;
-#if (GS_EXP & 1024)
-    const uint32_t exp_mode = getenv("GPUSORT_EXPMODE") ? (uint32_t)atoi(getenv("GPUSORT_EXPMODE")) & (256u | 512u | 1024u) : 0u;
+#if (GS_EXP & (1024 | 2048))
+    const uint32_t exp_mode = getenv("GPUSORT_EXPMODE") ? (uint32_t)atoi(getenv("GPUSORT_EXPMODE")) & (256u | 512u | 1024u | 2048u) : 0u;
     h->exp_keep_desc = (exp_mode & 256u) != 0u;
 #else
     const uint32_t exp_mode = 0u;

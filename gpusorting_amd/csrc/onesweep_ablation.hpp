@@ -42,6 +42,17 @@
 #define GS_ABL_NO_HEAVY_LAYOUT (((GS_EXP)&64) != 0)
 #define GS_ABL_LOOKBACK_SKIPPED (((GS_EXP)&1) != 0)
 #define GS_ABL_GENERIC_SCATTER (((GS_EXP)&(257 | 1024)) != 0)
+// 2048: what counting the NEXT digit per output position segment would cost inside the pass: one LDS add per
+//       key in the scatter loop, table [16 segments][256] behind the kernel's own LDS (never flushed: cost only); runtime
+//       mode bit 2048 switches it on, so the build's occupancy is the same with and without
+#if (GS_EXP & 2048)
+#define GS_ABL_COUNT_LDS 16384
+#define GS_ABL_COUNT_NEXT(kb, o) do { if (mode & 2048u) atomicAdd(reinterpret_cast<uint32_t*>(s_raw + Cfg::LDS_BYTES - 16384) + \
+        ((((o) >> (32u - __builtin_clz((n - 1u) >> 4))) & 15u) << 8) + (((kb) >> ((shift + 8u) & 31u)) & 255u), 1u); } while (0)
+#else
+#define GS_ABL_COUNT_LDS 0
+#define GS_ABL_COUNT_NEXT(kb, o) do { } while (0)
+#endif
 // 1024: the look-back / scatter decomposition of round 3 (tools/r03_ablate.py); the variants are RUNTIME bits of the
 //       kernel's mode word (GPUSORT_EXPMODE, read by the host at every sort), so one build serves every combination:
 //         mode 256   replay: the descriptors of an identical earlier sort are still in the slab (the histogram kernel

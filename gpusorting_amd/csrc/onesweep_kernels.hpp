@@ -85,6 +85,8 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #define GS_ABL_EARLY_USE(v) do { } while (0)   // ... and take it in the look-back if it is INCLUSIVE
 #define GS_ABL_CLOCKS_BEGIN() do { } while (0)  // histogram kernel: shader clock against the 100 MHz wall clock
 #define GS_ABL_CLOCKS_END() do { } while (0)
+#define GS_ABL_COUNT_LDS 0                     // extra LDS of the next-digit counting experiment
+#define GS_ABL_COUNT_NEXT(kb, o) do { } while (0)
 #endif
 // (measured and dropped: issuing the first look-back read before the staging phase, -4 %: the early read mostly
 //  returns a not-yet-final row and the wait moves in front of staging)
@@ -180,6 +182,12 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && S
 #endif
 #ifndef GS_HIST_UNROLL
 #define GS_HIST_UNROLL 4
+#endif
+#ifndef GS_HIST_NT
+#define GS_HIST_NT 1  // non-temporal key loads in the histogram kernel: 0.296 -> 0.250 ms at 2^28 (the pass that follows pays 0.008 ms
+                     // of it back: fewer of its first reads hit the memory-side cache), profiles/r03_ab_hist_nt_loads.txt.  Measured
+                     // with it and not kept: the next work item's loads in flight while this one is counted (no change: the kernel
+                     // does not wait for its loads)
 #endif
 #ifndef GS_HIST_REPLICAS
 #define GS_HIST_REPLICAS 1  // pass-0 digit counts on 32 lane-private, bank-conflict-free replicas (see global_histogram_kernel)
@@ -459,13 +467,22 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         const uint2 b = to_bits2<KT>(uint2{lo, hi});
         return word ? b.y : b.x;
     };
+    typedef uint32_t hv4 __attribute__((ext_vector_type(4)));
+    auto ld16 = [](const uint4* q) -> uint4 {
+#if GS_HIST_NT
+        const hv4 v = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(q));
+        return uint4{v.x, v.y, v.z, v.w};
+#else
+        return *q;
+#endif
+    };
     auto load_chunk = [&](uint32_t c) -> uint4 {
         if constexpr (KW == 2) {
             const uint4* p = reinterpret_cast<const uint4*>(keys) + (size_t)c * (HIST_CHUNK / 2);
-            const uint4 a = p[tid], b2 = p[tid + GHIST_THREADS];
+            const uint4 a = ld16(p + tid), b2 = ld16(p + tid + GHIST_THREADS);
             return uint4{word_of(a.x, a.y), word_of(a.z, a.w), word_of(b2.x, b2.y), word_of(b2.z, b2.w)};
         } else {
-            const uint4 a = reinterpret_cast<const uint4*>(keys + (size_t)c * HIST_CHUNK)[tid];
+            const uint4 a = ld16(reinterpret_cast<const uint4*>(keys + (size_t)c * HIST_CHUNK) + tid);
             return uint4{to_bits<KT>(a.x), to_bits<KT>(a.y), to_bits<KT>(a.z), to_bits<KT>(a.w)};
         }
     };
@@ -479,7 +496,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #else
     const uint32_t c_first = blockIdx.x * HIST_UNROLL, c_step = gridDim.x * HIST_UNROLL, nchunks = nchunks_all;
 #endif
-    for (uint32_t c0 = c_first; c0 < nchunks; c0 += c_step) {
+    uint32_t c0 = c_first;
+    for (; c0 < nchunks; c0 += c_step) {
         if (c0 + HIST_UNROLL <= nchunks && (unsigned long long)(c0 + HIST_UNROLL) * HIST_CHUNK <= n) {
             // common case: HIST_UNROLL full chunks — UNCONDITIONAL loads (conditional ones get an
             // s_waitcnt vmcnt(0) each from the compiler and end up one at a time in flight)
@@ -734,7 +752,7 @@ struct BinCfg {
     static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : (VROUNDS == 2 ? TILE * 4 : TILE * ((VB == 8 || KW == 2) ? 8 : 4));
     // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
     static constexpr bool HEAVY = GS_HEAVY && VB == 0 && KW == 1;
-    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0);
+    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0) + GS_ABL_COUNT_LDS;
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
     // look-back wait is covered by its neighbours' work
@@ -1401,6 +1419,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             for (int j = 0; j < KPT; ++j) {
                 const uint32_t d = (kb[j] >> shift) & 255u;
                 st_stream(keys_out + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
+                GS_ABL_COUNT_NEXT(kb[j], s_gbase[d] + tid + j * THREADS);
                 if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
             }
         }

@@ -78,7 +78,7 @@ for mode in modes:
         if best is None or p["total"] < best["total"]:
             best = p
     print(f"mode {mode:4d}  total={best['total']:.3f} hist={best['global_histogram']:.3f} passes=[{best['pass0']:.3f} {best['pass1']:.3f} "
-          f"{best['pass2']:.3f} {best['pass3']:.3f}] sorted={oks}  # {names[mode]}")
+          f"{best['pass2']:.3f} {best['pass3']:.3f}] sorted={oks}  # {names.get(mode, '')}")
     sys.stdout.flush()
 
 if os.environ.get("R03_MODES_ONLY", "0") == "1":
