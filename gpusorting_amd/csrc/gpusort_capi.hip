@@ -6,7 +6,7 @@
 // 1 + 1 + 4 launch sequence, validation read-back.  Differences by design:
 //   - no clear launch at all (the reference: 6 cudaMemset, :301-309): the scan state is ONE contiguous slab that
 //     the GlobalHistogram kernel zeroes while it reads the keys; no host sync inside the sort (:318);
-//   - the pass plan (identity passes dropped, input buffer of each pass, skew / heavy-value handling) is made by
+//   - the pass plan (identity passes dropped, input buffer of each pass, skew handling, position chains) is made by
 //     the Scan kernel on the device;
 //   - descriptor rows = tiles + 1, so the last tile's publish to row tile+1
 //     stays in bounds (the reference overruns by 256 words when size==maxSize);
@@ -55,6 +55,23 @@ const BinLauncher g_vr2[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr,
 #else
 const BinLauncher g_vr2[2][3] = {{launch_bin<512, 32, 8, 0, 0, 2>, launch_bin<512, 32, 8, 1, 0, 2>, launch_bin<512, 32, 8, 2, 0, 2>},
                                  {launch_bin<512, 32, 8, 0, 1, 2>, launch_bin<512, 32, 8, 1, 1, 2>, launch_bin<512, 32, 8, 2, 1, 2>}};
+#endif
+
+// keys-only sorts of 32-bit keys on the default tile that the Scan kernel may plan on position chains (PF_POS, skewed keys): one
+// launch per pass of the dual kernel — persistent workgroups that run the plain or the position-chain form, as planned.
+// [last pass][key type]
+constexpr uint32_t POS_TILE = 512 * 24;  // tile of the counting position-chain passes (the next-digit table takes 16 KiB of LDS)
+template <int KT, bool LAST>
+void launch_dual(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc, uint32_t* counters,
+                 const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
+    hipLaunchKernelGGL((gs::digit_binning_dual_kernel<KT, LAST>), dim3(grid), dim3(512), 0, s, ka, kb, va, vb, desc, counters, info,
+                       hsub, status, n, shift, mode);
+}
+#ifdef GS_MINIMAL
+const BinLauncher g_dual[2][3] = {{launch_dual<0, false>, nullptr, nullptr}, {launch_dual<0, true>, nullptr, nullptr}};
+#else
+const BinLauncher g_dual[2][3] = {{launch_dual<0, false>, launch_dual<1, false>, launch_dual<2, false>},
+                                  {launch_dual<0, true>, launch_dual<1, true>, launch_dual<2, true>}};
 #endif
 
 struct Shape {
@@ -134,8 +151,8 @@ struct gs_onesweep {
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int mid_path;    // 1 = two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (default), 0 = the six-launch path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
-    int heavy;       // heavy-value position slices in keys-only sorts: 1 on (default), 0 off
-    uint32_t heavy_min_keys;  // ... from this many keys up (default 2^26; GPUSORT_HEAVY_MIN_LOG2, floor 2^22 in the kernel)
+    int pos_chains;  // keys-only sorts of skewed 32-bit keys run every pass on position chains: 1 allowed (default), 0 never
+    uint32_t pos_min_keys;  // ... from this many keys up (default 2^25 + 1: where the big tile shape takes over; GPUSORT_POS_MIN_LOG2)
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -161,12 +178,15 @@ size_t slab_words_for(uint32_t max_keys) {
     return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
 }
 
-using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 template <int KT>
 void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n,
-                 uint32_t seg_len0, uint32_t p0, uint32_t np, uint32_t word) {
+                 uint32_t seg_len0, uint32_t p0, uint32_t np, uint32_t word, uint32_t allow_pos) {
     hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, slab,
-                       used_words, n, seg_len0, p0, np, word);
+                       used_words, n, seg_len0, p0, np, word, allow_pos);
+}
+inline hipError_t zero_hist(gs_onesweep* h, hipStream_t s) {  // the HIST region: four joint tables + what the keys look like as a whole
+    return hipMemsetAsync(h->slab + SLAB_HIST, 0, gs::HIST_WORDS * sizeof(uint32_t), s);
 }
 const HistLauncher g_hist[6] = {launch_hist<0>, launch_hist<1>, launch_hist<2>, launch_hist<3>, launch_hist<4>, launch_hist<5>};
 inline bool is_key64(gs_key_type kt) { return (int)kt >= 3; }
@@ -191,6 +211,16 @@ uint32_t hist_blocks(uint32_t n) {
     return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
+// persistent workgroups of the position-chain pass: two per CU (76 KiB of LDS each)
+uint32_t pos_grid() {
+    static const uint32_t cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return (uint32_t)v;
+    }();
+    return 2u * cus;
+}
+
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 // Clears the scan state and runs GlobalHistogram + Scan for passes p0 .. p0+np-1
@@ -204,7 +234,8 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tiles = div_up(n, tile);
-    const uint32_t rows = tiles + 2 * gs::MAXCH + 2;  // every chain: its tiles (+1 partial) + row 0
+    // every chain: its tiles (+1 partial) + row 0; bit 2 of the plan: the sort may end up on the (smaller) position-chain tiles
+    const uint32_t rows = ((scan_plan & 4u) && POS_TILE < tile ? div_up(n, POS_TILE) : tiles) + 2 * gs::MAXCH + 2;
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
     // position segments of the first pass: equal, multiples of the histogram chunk
@@ -213,17 +244,18 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // The histogram kernel ACCUMULATES into HIST and relies on it being zero between calls (the first pass
     // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
     // between left it dirty: zero it here, once, instead of double counting silently.
-    if (h->hist_dirty) GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
+    if (h->hist_dirty) GS_HIP(zero_hist(h, s));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
-    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word);
+    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
+               (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
     hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan);
+                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
     if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->desc_stride = desc_stride;
@@ -341,7 +373,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     }
 #endif
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
-    int shape = (h->shape_auto && n <= mid_keys(vb)) ? MID_SHAPE : h->shape;
+    // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
+    const bool pos_size = h->skip_passes && h->rank_mode == 1 && vb == 0 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys;
+    int shape = (h->shape_auto && n <= mid_keys(vb) && !pos_size) ? MID_SHAPE : h->shape;
     if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
     const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
@@ -349,11 +383,12 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
     // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
     const uint32_t dyn = h->skip_passes ? 2u : 0u;
-    // bit 2: the heavy-value layout may be used (its counts are gathered in the LDS-atomic ranking path only)
-    // (measured: it pays for keys-only sorts; with values the counting costs more than the balanced chains
-    // gain, profiles/r01_entropy_*); GPUSORT_HEAVY=0 switches it off
-    // compiled into the keys-only kernels only; pays from 2^26 keys up (2^23..2^25: -3..-6 %, profiles/r01_heavy_threshold.txt)
-    const bool heavy = dyn && h->rank_mode == 1 && vb == 0 && !is_key64(kt) && h->heavy != 0 && n >= h->heavy_min_keys;
+    // bit 2: the sort may run on position chains in every pass (PF_POS; decided on the device: the histogram kernel finds the
+    // digit groups uneven, the Scan kernel plans accordingly) — every pass is then launched in both chain forms and the
+    // plan says which one works.  Keys-only sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; GPUSORT_POS=0
+    // switches it off.
+    const bool pos = dyn && h->rank_mode == 1 && vb == 0 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
+                     g_dual[0][kt] != nullptr && sh.threads == 512 && sh.kpt == 32;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: two rounds of histogram + scan + 4 passes — the low word's bytes, then (stable) the high word's.
@@ -369,17 +404,22 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (heavy ? 4u : 0u), shape, word);
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word);
         if (st != GS_OK) return st;
         for (uint32_t p = 0; p < 4; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
             const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
             // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
             const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
-            fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-               h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-               h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
-               mode | (two_forms ? 32u : 0u) | exp_mode);
+            if (pos)  // one launch serves both plans (persistent workgroups, two per CU)
+                g_dual[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+                                   h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
+                                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
+            else
+                fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+                   h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
+                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
+                   mode | (two_forms ? 32u : 0u) | exp_mode);
             if (two_forms)
                 g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                         h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
@@ -465,13 +505,14 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->rank_mode = 0;
     h->small_path = 1;
     if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
-    h->heavy = 1;
-    h->heavy_min_keys = 1u << 26;
-    if (const char* env = getenv("GPUSORT_HEAVY_MIN_LOG2")) {
+    h->pos_chains = 1;
+    h->pos_min_keys = (1u << 25) + 1u;
+    if (const char* env = getenv("GPUSORT_POS_MIN_LOG2")) {
         const int lg = atoi(env);
-        if (lg >= 22 && lg <= 30) h->heavy_min_keys = 1u << lg;
+        if (lg >= 20 && lg <= 30) h->pos_min_keys = 1u << lg;
     }
-    if (const char* env = getenv("GPUSORT_HEAVY")) h->heavy = atoi(env) ? 1 : 0;
+    if (const char* env = getenv("GPUSORT_POS")) h->pos_chains = atoi(env);  // 0 never, 1 when the keys are skewed, 2 always (tests, tuning)
+    if (h->pos_chains < 0 || h->pos_chains > 2) h->pos_chains = 1;
     h->skip_passes = 1;
     if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
     h->mid_path = 1;
@@ -657,7 +698,7 @@ gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream)
     if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) ret = GS_ERR_HIP;
     if (ret == GS_OK) {
         hipLaunchKernelGGL(gs::check_state_kernel, dim3(gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
-                           h->last_tile, 0u, h->last_dyn, d);
+                           h->last_tile, 0u, h->last_dyn, d, POS_TILE);
         if (hipMemcpyAsync(report, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             ret = GS_ERR_HIP;
@@ -676,7 +717,7 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
     if (st != GS_OK) return st;
     const size_t words = 4 * (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
+    GS_HIP(zero_hist(h, s));  // no pass follows: hand HIST back zeroed
     h->hist_dirty = false;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t q = 0; q < 4; ++q)  // digit totals = joint histogram summed over chains
@@ -732,7 +773,7 @@ gs_status gs_onesweep_msd_prepare(gs_onesweep* h, const void* d_keys, uint32_t n
     if (st != GS_OK) return st;
     const size_t words = (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // msd_partition may never be called
+    GS_HIP(zero_hist(h, s));  // msd_partition may never be called
     h->hist_dirty = false;
     GS_HIP(hipStreamSynchronize(s));
     for (uint32_t d = 0; d < gs::RADIX; ++d) {
@@ -874,7 +915,7 @@ gs_status gs_onesweep_msd_fine_histogram(gs_onesweep* h, const void* d_keys, uin
     if (st != GS_OK) return st;
     const size_t words = 2 * (size_t)gs::NCH * gs::RADIX;
     GS_HIP(hipMemcpyAsync(h->pinned, h->slab + SLAB_HIST, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, words * sizeof(uint32_t), s));  // no pass follows: hand HIST back zeroed
+    GS_HIP(zero_hist(h, s));  // no pass follows: hand HIST back zeroed
     h->hist_dirty = false;
     if (h->profiling)  // slots 0..2 (clear, histogram, scan) are this call's; the pass slots read 0
         for (int e = 4; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));

@@ -178,7 +178,7 @@ gs_status mgpu_plan(gs_mgpu* c, const void* d_keys, uint32_t n, gs_key_type kt, 
     if (st != GS_OK) return st;
     hipLaunchKernelGGL(gs::msd_fold_kernel, dim3(nbins / 256), dim3(256), 0, s, h->slab + SLAB_HIST, nbins, c->d_hist);
     if (fine) {  // no pass follows this prologue: hand HIST back zeroed
-        GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
+        GS_HIP(zero_hist(h, s));
         h->hist_dirty = false;
     }
     if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, nbins, s) != 0) return GS_ERR_COMM;
@@ -309,7 +309,7 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
             // every rank sees the same gathered table and takes the same decision: split at the 12-bit prefix
             fine = true;
             if (n) {  // the top-byte scan state is abandoned: its histogram region must be handed back zeroed
-                GS_HIP(hipMemsetAsync(h->slab + SLAB_HIST, 0, 4 * (size_t)gs::NCH * gs::RADIX * sizeof(uint32_t), s));
+                GS_HIP(zero_hist(h, s));
                 h->hist_dirty = false;
                 gs_status st = mgpu_plan(c, d_keys, n, kt, s, true, &pp);
                 if (st != GS_OK) return st;

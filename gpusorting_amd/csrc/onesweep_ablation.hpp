@@ -9,7 +9,6 @@
 //       its descriptor, as if its workgroup had stalled.  With the fallback (default) its successors recount it and
 //       the sort is exact; with -DGS_FALLBACK=0 every later tile of that chain runs into the bounded spin, the sort
 //       still finishes, and gs_onesweep_check says GS_ERR_TIMEOUT.
-//   16 / 32  heavy-value counting / flush off;  64  heavy layout not used (counting still runs)
 //   256 no look-back wait with the real scatter shape: every earlier tile of the chain is assumed to hold this
 //       tile's digit counts (positions approximate, wrapped into range)
 #pragma once
@@ -37,9 +36,6 @@
 #define GS_ABL_HIST_STREAM_ONLY(t) do { } while (0)
 #endif
 
-#define GS_ABL_NO_HEAVY_COUNT (((GS_EXP)&16) != 0)
-#define GS_ABL_NO_HEAVY_FLUSH (((GS_EXP)&32) != 0)
-#define GS_ABL_NO_HEAVY_LAYOUT (((GS_EXP)&64) != 0)
 #define GS_ABL_LOOKBACK_SKIPPED (((GS_EXP)&1) != 0)
 #define GS_ABL_GENERIC_SCATTER (((GS_EXP)&(257 | 1024)) != 0)
 // 2048: what counting the NEXT digit per output position segment would cost inside the pass: one LDS add per

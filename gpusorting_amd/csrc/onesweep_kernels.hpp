@@ -26,8 +26,8 @@
 //   * descriptors are single dwords {count:30, flag:2} accessed with relaxed
 //     agent-scope atomics (sc1): the data IS the flag, no fences.
 //   * everything is decided on the device, nothing needs a host round trip: the Scan kernel plans the passes
-//     (identity passes are dropped in pairs, a skewed pass ranks with wave-aggregated adds, a digit value holding
-//     most keys gets its run split into position chains in the next pass), and a look-back that waits too long
+//     (identity passes are dropped in pairs, a skewed pass ranks with wave-aggregated adds, a skewed SORT runs every pass on
+//     position chains whose bases the pass before counts while it scatters), and a look-back that waits too long
 //     recounts the missing tile itself, so no workgroup depends on another's progress for more than a bounded time.
 //   * a sort is 6 launches: GlobalHistogram (which also clears the scan state), Scan, 4 x DigitBinningPass.
 #pragma once
@@ -73,9 +73,6 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #define GS_TRACE_TRIP() do { } while (0)
 #define GS_TRACE_END(chain) do { } while (0)
 #define GS_ABL_HIST_STREAM_ONLY(t) do { } while (0)   // histogram kernel: stream the keys, count nothing
-#define GS_ABL_NO_HEAVY_LAYOUT false           // heavy-value chains not used although counted
-#define GS_ABL_NO_HEAVY_COUNT false            // heavy-value counting off
-#define GS_ABL_NO_HEAVY_FLUSH false            // heavy-value counts not handed to the next pass
 #define GS_ABL_LOOKBACK_SKIPPED false          // no look-back wait
 #define GS_ABL_ASSUME_PREV() do { } while (0)  // no wait, positions extrapolated from this tile's own counts
 #define GS_ABL_GENERIC_SCATTER false           // force the generic (masked) scatter loops
@@ -101,11 +98,6 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #endif
 constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 
-#ifndef GS_HEAVY
-#define GS_HEAVY 1  // a digit value holding more than half of the keys gets its region of the NEXT pass's input split into NCH
-                    // position sub-chains; the joint counts those chains need are gathered by the pass that writes
-                    // the region (see "heavy digit" in DESIGN.md).  0 = digit-group chains only.
-#endif
 #ifndef GS_FUSED_PAIRS
 #define GS_FUSED_PAIRS 1  // (key, u32 value) pairs staged and scattered together (BinCfg::FUSED)
 #endif
@@ -115,19 +107,10 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
                         // staging phase and consumed after it +3 / +5 / +6 % — an INCLUSIVE row is further back than that
                         // when the request is issued, so the walk repeats the reads and the chip only moved more bytes
 #endif
-#ifndef GS_HEAVY_SHARE
-#define GS_HEAVY_SHARE 2u  // "heavy" = more than n / GS_HEAVY_SHARE keys.  Measured with 4: at a 34 % value the slices
-                           // gain nothing over the digit-group chains and the counting still costs
-#endif
-#ifndef GS_HEAVY_MIN_KEYS
-#define GS_HEAVY_MIN_KEYS (1u << 22)  // below this a sub-chain would be shorter than a few tiles
-#endif
-// Chains of a pass.  Normal: chain c < NCH = position segment (first pass) or group of the previous digit.
-// Heavy (digit value h of the previous digit holds more than half of the keys): chains 0..NCH-1 = equal position slices of h's
-// region; NCH + x = digit group x (group x_h = h >> 4 keeps only its digits below h); 2*NCH = the digits of
-// group x_h above h.  Every chain is one contiguous range of the pass's input.
-constexpr uint32_t MAXCH = 2 * NCH + 1;
-static_assert(!GS_HEAVY || MAXCH <= 64, "heavy-digit sub-chains need 2*NCH+1 <= 64 lanes");
+// Chains of a pass: chain c < NCH = position segment of the pass's input (first pass of every sort; every pass of a sort
+// planned on position chains, PF_POS) or group of the previous digit's values (NCH consecutive values per chain).  Every
+// chain is one contiguous range of the pass's input.
+constexpr uint32_t MAXCH = NCH;
 
 // per-pass info block (uint32 words), written by scan_kernel
 constexpr uint32_t I_START = 0;                // seg_start[MAXCH]
@@ -135,10 +118,9 @@ constexpr uint32_t I_END = MAXCH;              // seg_end[MAXCH]
 constexpr uint32_t I_ROW = 2 * MAXCH;          // first descriptor row of each chain
 constexpr uint32_t PASS_FLAGS = 3 * MAXCH;     // PF_* bits
 constexpr uint32_t I_NCH = PASS_FLAGS + 1;     // chains in use (NCH or MAXCH)
-constexpr uint32_t I_CNT_H = PASS_FLAGS + 2;   // this pass gathers counts for the next one: heavy value of ITS digit (else ~0)
-constexpr uint32_t I_CNT_START = PASS_FLAGS + 3;   //   first output position of that value's run
-constexpr uint32_t I_CNT_SUBLEN = PASS_FLAGS + 4;  //   keys per position slice
-constexpr uint32_t I_XH = PASS_FLAGS + 5;          // heavy layout: digit group of the heavy value
+constexpr uint32_t I_NEXT_SHIFT = PASS_FLAGS + 2;  // PF_POS: bit position of the digit of the next pass that runs (this pass counts it per
+                                                   // output position segment while it scatters), ~0 = nothing to count
+constexpr uint32_t I_SEGLOG = PASS_FLAGS + 3;      // PF_POS: log2 of the position segments of the passes behind the first one
 constexpr uint32_t I_MODE = PASS_FLAGS + 6;        // PF_SKEW passes: the most frequent value of this pass's digit
 constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 7 + 31) / 32) * 32;
 constexpr uint32_t PF_SKEW = 1;    // some digit holds >= n/8 keys: rank with wave-aggregated adds
@@ -146,15 +128,19 @@ constexpr uint32_t PF_SKIP = 2;     // every key has the same digit AND the pass
                                     // passes: the pass is the identity permutation, its workgroups exit at once
 constexpr uint32_t PF_SRC_ALT = 4;  // an odd number of earlier passes ran: this pass reads alt and writes keys
 constexpr uint32_t PF_LAST = 8;     // last pass that runs: applies the descending index reversal
-constexpr uint32_t PF_HEAVY = 16;   // heavy chain layout: tile 0 of chains 0..NCH-1 and 2*NCH seeds itself from HSUB
+constexpr uint32_t PF_POS = 16;     // the sort runs on position chains in EVERY pass (skewed keys: digit-group chains would be
+                                    // as uneven as the digit values).  Behind the first pass nobody knows the chains' bases
+                                    // upfront: each pass counts the next pass's digit per output position segment while it
+                                    // scatters (CNEXT), every workgroup of the next pass derives digit starts / skew / mode digit
+                                    // from those counts when it starts, and tile 0 of each chain seeds the chain's row 0
 
 // ---- state slab layout (uint32 words), shared by host and kernels -------------
 //  COUNTERS  tile tickets, [pass][chain]                       (reference m_index)
 //  STATUS    device status word
 //  INFO      per pass: the info block above                    (written by scan_kernel)
 //  HIST      joint histograms H[pass][chain][digit]            (reference m_globalHistogram)
-//  HSUB      per pass q: [NCH slices + 1][256] counts of digit q among the keys whose digit q-1 is the heavy
-//            value (by position slice of the pass's input) / lies below it inside its group
+//  HSUB      CNEXT[pass q][segment x][digit d]: keys in position segment x of pass q's INPUT whose digit q is d — counted by the
+//            pass that wrote that input (sorts planned on position chains, PF_POS); rows of NCH + 1 x 256 words per pass
 //  DESC      descriptors: pass q at DESC + q*desc_stride, rows of 256 words
 constexpr uint32_t SLAB_COUNTERS = 0;
 constexpr uint32_t COUNTER_STRIDE = 32;  // one 128-byte line per ticket counter: chains do not share a line
@@ -163,7 +149,11 @@ static_assert(COUNTERS_PER_PASS >= MAXCH, "ticket counters");
 constexpr uint32_t SLAB_STATUS = 4 * COUNTERS_PER_PASS * COUNTER_STRIDE;
 constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
 constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
-constexpr uint32_t SLAB_HSUB = SLAB_HIST + 4 * NCH * RADIX;
+// behind the four joint tables: what else the histogram kernel tells the Scan kernel (zero between calls, like the tables)
+constexpr uint32_t HIST_TABLE_WORDS = 4 * NCH * RADIX;
+constexpr uint32_t HX_SKEW = 0;  // a workgroup found the digit groups of its keys uneven and stopped counting the joint tables
+constexpr uint32_t HIST_WORDS = HIST_TABLE_WORDS + 32;
+constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): barrier counter, route flag, bucket table,
 // two count tables of MID_MAX_TILES rows
@@ -188,6 +178,10 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && S
                      // of it back: fewer of its first reads hit the memory-side cache), profiles/r03_ab_hist_nt_loads.txt.  Measured
                      // with it and not kept: the next work item's loads in flight while this one is counted (no change: the kernel
                      // does not wait for its loads)
+#endif
+#ifndef GS_POS_SHARE
+#define GS_POS_SHARE 3u  // a digit group holding more than GS_POS_SHARE / 16 of a workgroup's first 16 384 keys (even: 1 / 16) sends the
+                         // sort to the position-chain kernels
 #endif
 #ifndef GS_HIST_REPLICAS
 #define GS_HIST_REPLICAS 1  // pass-0 digit counts on 32 lane-private, bank-conflict-free replicas (see global_histogram_kernel)
@@ -276,7 +270,7 @@ __device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
 
 template <int N>
 struct IntTag { static constexpr int value = N; };
-// block placement: the rare paths (steal, partial tiles, skew, fallback, heavy-value bookkeeping) tripled the
+// block placement: the rare paths (steal, partial tiles, skew, fallback) tripled the
 // kernel's code; keeping the common path contiguous keeps it in the instruction cache
 #define GS_LIKELY(x) __builtin_expect(!!(x), 1)
 #define GS_UNLIKELY(x) __builtin_expect(!!(x), 0)
@@ -339,9 +333,13 @@ template <int KT>
 __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                          uint32_t* slab, size_t slab_used_words,
                                                                          uint32_t n, uint32_t seg_len0, uint32_t p0,
-                                                                         uint32_t np, uint32_t word) {
+                                                                         uint32_t np, uint32_t word,
+                                                                         uint32_t allow_pos /*1: the sort may run on position
+                                                                         chains (scan_kernel, PF_POS) — uneven digit groups end the
+                                                                         counting of the joint tables*/) {
     constexpr int KW = KeyWords<KT>::value;
     __shared__ uint32_t s_h[4 * NCH * RADIX];
+    __shared__ uint32_t s_uneven;  // a digit group of this workgroup's first work item holds more than GS_POS_SHARE of its keys
 #if GS_HIST_REPLICAS
     // Pass-0 digit counts on 32 lane-private replicas, 16-bit counters packed two per dword: dword (d >> 1) * 32 +
     // (lane & 31) lies in bank lane & 31, so a wave's add never meets a bank conflict — whatever the keys are: the
@@ -370,6 +368,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     }
     const uint32_t bins = np * NCH * RADIX;
     for (uint32_t i = tid; i < bins; i += GHIST_THREADS) s_h[i] = 0;
+    if (tid == 0) s_uneven = 0;
+    bool joint_off = (allow_pos & 2u) != 0u;  // uniform: the joint tables are given up (see the probe behind the first work item; bit 1: from the start)
 #if GS_HIST_REPLICAS
     for (uint32_t i = tid; i < RADIX / 2 * 32; i += GHIST_THREADS) s_r[i] = 0;
     uint32_t cur_x0 = 0xffffffffu, since_fold = 0;  // uniform: segment the replicas are counting for, chunks since the last fold
@@ -401,7 +401,9 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
     // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
     constexpr uint32_t HIST_UNROLL = GS_HIST_UNROLL;
-    auto process = [&](const uint4 t, const uint32_t x0, const bool probe) {  // t: four keys' digit words, sortable form
+    // JOINT = 0: the joint tables are given up (joint_off) — only the first digit is counted
+    auto process = [&](auto joint_tag, const uint4 t, const uint32_t x0, const bool probe) {  // t: four keys' digit words, sortable form
+            constexpr bool JOINT = decltype(joint_tag)::value != 0;
             GS_ABL_HIST_STREAM_ONLY(t);
             const uint32_t b[4] = {t.x, t.y, t.z, t.w};
 #if GS_HIST_REPLICAS
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #endif
 #pragma unroll
             for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < 4; ++q) {
-                if (q < np) {
+                if (q < np && (JOINT || q == 0)) {
                     uint32_t bin[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], q, x0);
@@ -504,8 +506,31 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             uint4 t[HIST_UNROLL];
 #pragma unroll
             for (uint32_t u = 0; u < HIST_UNROLL; ++u) t[u] = load_chunk(c0 + u);
+            if (GS_LIKELY(!joint_off)) {
 #pragma unroll
-            for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
+                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<1>{}, t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<0>{}, t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
+            }
+            if (allow_pos && c0 == c_first && !joint_off) {
+                // Are the digit groups even?  The chains of passes 1..3 are the NCH groups of the previous digit's values:
+                // with skewed keys (Thearling-Smith presets 2..5: group 0 holds 32 .. 88 % of them) one chain gets most
+                // tiles and commits in order, and the joint tables themselves cost 2-3x (same-address LDS adds).  The
+                // first work item (16 384 keys) is the sample: a group above GS_POS_SHARE / 16 of it ends the joint
+                // counting HERE and tells the Scan kernel to plan the sort on position chains (HX_SKEW); the tables
+                // of other workgroups that go on counting are simply not used.
+                __syncthreads();
+                if (tid < 3 * NCH) {
+                    const uint32_t q = 1u + tid / NCH, x = tid % NCH;
+                    uint32_t c = 0;
+                    for (uint32_t d = 0; d < RADIX; ++d) c += s_h[hist_index(q, d, x)];
+                    // (a group holding EVERY key of the sample: a constant byte — its pass is dropped, not a crowded chain)
+                    if (q < np && c > (HIST_UNROLL * HIST_CHUNK / 16u) * GS_POS_SHARE && c != HIST_UNROLL * HIST_CHUNK) s_uneven = 1u;
+                }
+                __syncthreads();
+                joint_off = joint_off || s_uneven != 0u;
+            }
             continue;
         }
         uint4 t[HIST_UNROLL];
@@ -520,11 +545,13 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             if (c0 + u < nchunks) {
                 const uint32_t x0 = base / seg_len0;  // uniform: a whole chunk lies in one position segment
                 if (base + HIST_CHUNK <= n) {
-                    process(t[u], x0, true);
+                    if (joint_off) process(IntTag<0>{}, t[u], x0, true);
+                    else process(IntTag<1>{}, t[u], x0, true);
                 } else {
                     for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
                         const uint32_t kb = KW == 2 ? word_of(keys[2 * (size_t)i], keys[2 * (size_t)i + 1]) : to_bits<KT>(keys[i]);
-                        for (uint32_t q = 0; q < np; ++q) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
+                        for (uint32_t q = 0; q < np; ++q)
+                            if (!(joint_off && q >= 1)) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
                     }
                 }
             }
@@ -539,6 +566,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         const uint32_t v = s_h[i];
         if (v) atomicAdd(&hist[i], v);
     }
+    // (measured: accumulating the OR / AND of all keys here, to drop constant bytes in position-chain sorts too, cost 0.08 ms)
+    if (tid == 0 && joint_off) atomicOr(&hist[HIST_TABLE_WORDS + HX_SKEW], 1u);
     GS_ABL_CLOCKS_END();
 }
 
@@ -553,15 +582,14 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_t* desc, uint32_t* info,
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
                                                     uint32_t seg_len0, uint32_t tile_keys,
-                                                    uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip
-                                                                    identity passes, bit2 (with bit1): heavy layout allowed*/) {
+                                                    uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip identity
+                                                                    passes, bit2 (with bit1): position chains in every pass allowed*/,
+                                                    uint32_t tile_keys_pos /*tile of the position-chain kernels (bit2)*/) {
     __shared__ uint32_t s_wtot[2][4];
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_start[MAXCH], s_end[MAXCH], s_rowbase[MAXCH + 1];
     __shared__ uint32_t s_triv;
-    __shared__ unsigned long long s_best[2];  // heaviest value of [0] the previous digit (this pass's layout), [1] this digit
     __shared__ unsigned long long s_mode;     // most frequent value of this digit, if it holds more than 1/8 of the keys
-    __shared__ uint32_t s_hv[2][2];           // its run start and count
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
@@ -570,6 +598,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     // histogram (rows of passes that were not counted are zero).  The kernel is a serial step of every sort;
     // with the loads strung out behind each other it took 11 us.
     uint32_t hq[NCH], g_all[4], g = 0, gprev = 0;
+    const uint32_t hx_skew = hist[HIST_TABLE_WORDS + HX_SKEW];
     {
         uint32_t h[4][NCH];
 #pragma unroll
@@ -587,27 +616,27 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
 #pragma unroll
         for (uint32_t x = 0; x < NCH; ++x) hq[x] = q == 0 ? h[0][x] : q == 1 ? h[1][x] : q == 2 ? h[2][x] : h[3][x];
     }
-    if (tid == 0) { s_triv = 0; s_best[0] = 0; s_best[1] = 0; s_mode = 0; }
+    // Position chains in every pass (PF_POS): some workgroup of the histogram kernel found the digit groups of its keys
+    // uneven and stopped counting the joint tables — they are incomplete, only the first digit's position histogram
+    // (hq of pass 0) and the OR / AND of all keys are whole.  Uniform: every workgroup reads the same words.
+    const bool pos = (plan & 6u) == 6u && hx_skew != 0u;
+    if (tid == 0) { s_triv = 0; s_mode = 0; }
     __syncthreads();
 
     // ---- which passes run (full sorts only).  A pass whose digit is the same for every key is the identity
     // permutation; such passes are dropped in PAIRS, so the result still lands in the caller's buffer with no
     // extra copy and no host round trip: every workgroup of a dropped pass exits on its flag word, every other
     // pass learns from its flags which buffer it reads.  A descending sort keeps one pass to do the reversal.
-    if (plan & 2u) {
+    // (Position chains: all four passes run — the digit totals behind the first digit are not known here.  A workgroup
+    //  of the histogram kernel whose sample shows a byte with ONE value does not count that byte as uneven, so keys with
+    //  constant bytes and otherwise even digits stay on this path.)
+    if ((plan & 2u) && !pos) {
 #pragma unroll
         for (uint32_t qq = 0; qq < 4; ++qq)
             if (g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
     }
-    // ---- heavy values (full sorts of >= GS_HEAVY_MIN_KEYS keys): a digit count above n / GS_HEAVY_SHARE (the
-    // largest, ties to the smaller digit).  Workgroup q decides the layout of pass q from digit q-1 and what pass q must count
-    // for pass q+1 from digit q; workgroup q+1 reads the same totals, so both sides agree.
-    const bool heavy_on = GS_HEAVY && (plan & 4u) && n >= GS_HEAVY_MIN_KEYS;
-    if (heavy_on) {
-        if (q >= 1 && gprev > n / GS_HEAVY_SHARE) atomicMax(&s_best[0], ((unsigned long long)gprev << 8) | (255u - tid));
-        if (q < 3 && g > n / GS_HEAVY_SHARE) atomicMax(&s_best[1], ((unsigned long long)g << 8) | (255u - tid));
-    }
-    if (g >= (n >> 3) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
+    const bool counted = !pos || q == 0;  // this pass's digit totals g and chain rows hq are complete
+    if (counted && g >= (n >> 3) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
     // digit scans of this pass's totals and (for the segment starts) of the previous digit's totals
     const uint32_t incl = wave_inclusive_scan(g, lane);
     const uint32_t incl_prev = wave_inclusive_scan(gprev, lane);
@@ -623,28 +652,29 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         for (uint32_t qq = 0; qq < 4 && drop; ++qq)
             if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
     }
-    uint32_t h_use = 0xffffffffu, h_cnt = 0xffffffffu;  // uniform
-    if (heavy_on) {
-        // the slices of pass q are counted by pass q-1 while it writes them: both passes must run
-        if (!GS_ABL_NO_HEAVY_LAYOUT && q >= 1 && s_best[0] != 0 && ((skip >> (q - 1)) & 3u) == 0u) h_use = 255u - (uint32_t)(s_best[0] & 255u);
-        if (q < 3 && s_best[1] != 0 && ((skip >> q) & 3u) == 0u) h_cnt = 255u - (uint32_t)(s_best[1] & 255u);
-    }
-    if (tid == h_use) { s_hv[0][0] = base_prev + incl_prev - gprev; s_hv[0][1] = gprev; }
-    if (tid == h_cnt) { s_hv[1][0] = base + incl - g; s_hv[1][1] = g; }
+    const uint32_t run_mask = ~skip & 15u;
     if ((plan & 2u) && tid == 0) {
-        const uint32_t run = ~skip & 15u;
         uint32_t f = 0;
         if ((skip >> q) & 1u) f |= PF_SKIP;
-        if (__popc(run & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
-        if (run && q == 31u - (uint32_t)__clz(run)) f |= PF_LAST;
-        if (h_use != 0xffffffffu) f |= PF_HEAVY;
+        if (__popc(run_mask & ((1u << q) - 1u)) & 1) f |= PF_SRC_ALT;
+        if (run_mask && q == 31u - (uint32_t)__clz(run_mask)) f |= PF_LAST;
+        if (pos) f |= PF_POS;
         if (f) atomicOr(&my_info[PASS_FLAGS], f);
     }
+    // position segments behind the first pass (PF_POS): a power of two, so the pass in front finds a key's segment
+    // with one shift of its output index
+    const uint32_t seglog = 32u - (uint32_t)__clz((((n + NCH - 1u) / NCH) - 1u) | 1u);
 
-    // segment starts: q == 0 position segments; q >= 1 starts of the digit-(q-1) groups
+    // segment starts: position segments (first pass: multiples of the histogram's chunk; PF_POS: powers of two);
+    // otherwise starts of the digit-(q-1) groups
     if (q == 0) {
         if (tid <= NCH) {
             const unsigned long long s = (unsigned long long)tid * seg_len0;
+            s_cum[tid] = s < n ? (uint32_t)s : n;
+        }
+    } else if (pos) {
+        if (tid <= NCH) {
+            const unsigned long long s = (unsigned long long)tid << seglog;
             s_cum[tid] = s < n ? (uint32_t)s : n;
         }
     } else {
@@ -657,36 +687,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         if (tid <= NCH) s_cum[tid] = v;  // compact: s_cum[x] = start of digit group x
     }
     __syncthreads();
-    // chains (see MAXCH): every chain one contiguous range [start, end) of this pass's input
-    auto slice_len = [](uint32_t count) { return ((count + NCH - 1) / NCH + 63u) & ~63u; };
     if (tid < MAXCH) {
-        uint32_t st = 0, en = 0;
-        if (h_use == 0xffffffffu) {
-            if (tid < NCH) { st = s_cum[tid]; en = s_cum[tid + 1]; }
-        } else {
-            const uint32_t hs = s_hv[0][0], he = hs + s_hv[0][1], sl = slice_len(s_hv[0][1]);
-            const uint32_t xh = h_use / (RADIX / NCH);
-            if (tid < NCH) {  // slices of the heavy value's run
-                const uint32_t a = hs + tid * sl;
-                st = a < he ? a : he;
-                en = a + sl < he ? a + sl : he;
-            } else if (tid < 2 * NCH) {  // digit groups; the heavy value's group keeps the digits below it
-                const uint32_t x = tid - NCH;
-                st = s_cum[x];
-                en = x == xh ? hs : s_cum[x + 1];
-            } else {  // the digits above the heavy value inside its group
-                st = he;
-                en = s_cum[xh + 1];
-            }
-        }
-        s_start[tid] = st;
-        s_end[tid] = en;
+        s_start[tid] = s_cum[tid];
+        s_end[tid] = s_cum[tid + 1];
     }
     __syncthreads();
     // first descriptor row of every chain: a wave-level scan over the chains' row counts
     if (wave == 0) {
         uint32_t rows = 0;
-        if (lane < MAXCH) rows = chain_tiles(s_start[lane], s_end[lane], tile_keys) + 1u;
+        // (PF_POS: the passes that count for a successor run on the smaller tile, the last one on the full-size tile)
+        if (lane < MAXCH) rows = chain_tiles(s_start[lane], s_end[lane], (pos && q != 3u) ? tile_keys_pos : tile_keys) + 1u;
         const uint32_t rincl = wave_inclusive_scan(rows, lane);
         if (lane <= MAXCH) s_rowbase[lane] = rincl - rows;
     }
@@ -697,26 +707,24 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         my_info[I_ROW + tid] = s_rowbase[tid];
     }
     if (tid == 0) {
-        my_info[I_NCH] = h_use == 0xffffffffu ? NCH : MAXCH;
-        my_info[I_XH] = h_use == 0xffffffffu ? 0u : h_use / (RADIX / NCH);
-        my_info[I_CNT_H] = h_cnt;
-        my_info[I_CNT_START] = h_cnt == 0xffffffffu ? 0u : s_hv[1][0];
-        my_info[I_CNT_SUBLEN] = h_cnt == 0xffffffffu ? 1u : slice_len(s_hv[1][1]);
+        my_info[I_NCH] = NCH;
+        // the pass behind this one that runs: this pass counts ITS digit per output segment (PF_POS)
+        const uint32_t later = run_mask & ~((2u << q) - 1u);
+        my_info[I_NEXT_SHIFT] = (pos && later) ? 8u * (uint32_t)__builtin_ctz(later) : 0xffffffffu;
+        my_info[I_SEGLOG] = seglog;
         my_info[I_MODE] = s_mode ? 255u - (uint32_t)(s_mode & 255u) : 0xffffffffu;
     }
+    if (!counted) return;  // PF_POS behind the first pass: the pass's own workgroups derive skew flag, mode digit and seeds
 
     // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
     // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
-    const unsigned long long heavy = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
-    if (lane == 0 && heavy) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
-    // digit starts and chain bases.  Heavy layout: the group chains (NCH + x) are seeded here; the slices and
-    // the upper part of the heavy group depend on counts gathered by the previous pass — tile 0 of each of
-    // those chains seeds its own row 0 when it starts (digit_binning_kernel).
+    const unsigned long long skewed = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
+    if (lane == 0 && skewed) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
+    // digit starts and chain bases
     uint32_t run = base + incl - g;  // dstart[tid]
-    const uint32_t first = h_use == 0xffffffffu ? 0u : NCH;
 #pragma unroll
     for (uint32_t x = 0; x < NCH; ++x) {
-        my_desc[(size_t)s_rowbase[first + x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
+        my_desc[(size_t)s_rowbase[x] * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
         run += hq[x];
     }
 }
@@ -734,7 +742,7 @@ struct ValT { using type = uint32_t; };
 template <>
 struct ValT<8> { using type = uint64_t; };
 
-template <int THREADS, int KPT, int VB, int KW = 1, int VR = 1>
+template <int THREADS, int KPT, int VB, int KW = 1, int VR = 1, int POS = 0>
 struct BinCfg {
     static constexpr int WAVES = THREADS / 64;
     static constexpr int TILE = THREADS * KPT;
@@ -750,9 +758,12 @@ struct BinCfg {
     // crowded chain) — so both forms are compiled and the pass's PF_SKEW flag picks one on the device (mode bits 4, 5).
     static constexpr int VROUNDS = (VR == 2 && VB == 8 && KW == 1 && !FUSED) ? 2 : 1;
     static constexpr int STAGE_BYTES = FUSED ? TILE * (4 + VB) : (VROUNDS == 2 ? TILE * 4 : TILE * ((VB == 8 || KW == 2) ? 8 : 4));
-    // heavy-value counting exists in the keys-only kernels only (with values it costs more than it gains)
-    static constexpr bool HEAVY = GS_HEAVY && VB == 0 && KW == 1;
-    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + (HEAVY ? 2 * RADIX * 4 : 0) + GS_ABL_COUNT_LDS;
+    // POS = 1, the position-chain form of the pass (sorts planned with PF_POS): persistent workgroups that count the next
+    // pass's digit per output position segment while they scatter — table [NCH][256] kept for the workgroup's whole life —
+    // and derive the pass's digit starts from the counts of the pass before (256 words + 8)
+    // POS = 2: the same without the counting and its table — the last pass of such a sort, on full-size tiles
+    static constexpr int POS_BYTES = POS == 1 ? (NCH * RADIX * 4 + RADIX * 4 + 32) : POS == 2 ? (RADIX * 4 + 32) : 0;
+    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + POS_BYTES + GS_ABL_COUNT_LDS;
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
     // look-back wait is covered by its neighbours' work
@@ -768,20 +779,25 @@ struct BinCfg {
         WAVES_PER_SIMD_RAW < WAVES_PER_SIMD_CAP ? WAVES_PER_SIMD_RAW : WAVES_PER_SIMD_CAP;
 };
 
-template <int THREADS, int KPT, int VB, int KT, int RANK, int VR = 1>
-__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::WAVES_PER_SIMD)) void digit_binning_kernel(
+// The pass as a device function: one tile (PERSIST = false: one workgroup per tile, the grid covers the tiles) or tile after
+// tile until every chain is claimed (PERSIST = true).  s_raw: Cfg::LDS_BYTES of LDS.
+template <int THREADS, int KPT, int VB, int KT, int RANK, int VR, int POS, bool PERSIST>
+__device__ __forceinline__ void binning_body(
+    unsigned char* s_raw,
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b,  // the pass reads a and writes b, unless ...
     uint32_t* desc,          // this pass: rows of 256 descriptor words; chain x starts at row_base[x]
     uint32_t* counters,      // this pass: one ticket counter per chain
     const uint32_t* info,    // this pass: the info block written by scan_kernel
-    uint32_t* hsub,          // SLAB_HSUB: read [pass] (heavy layout), added to [pass + 1] (counting pass)
+    uint32_t* hsub,          // SLAB_HSUB = CNEXT (PF_POS sorts): read [this pass], added to [the next pass that runs]
     uint32_t* status, uint32_t n, uint32_t shift_full /*bit position of the digit in the key: 0..24, 64-bit keys 0..56*/,
     uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
                     on the last pass that runs (PF_LAST); bit2: zero the HIST region; bit4 / bit5: this launch is one of two
-                    forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5)*/) {
+                    forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5); bit6: the
+                    pass is launched in BOTH chain forms — this one works only if the plan's PF_POS matches its POS*/) {
     constexpr int KW = KeyWords<KT>::value;
-    using Cfg = BinCfg<THREADS, KPT, VB, KW, VR>;
+    using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
+    static_assert(!POS || (VB == 0 && KW == 1 && RANK == 1), "the position-chain form exists for 32-bit keys-only sorts, LDS-atomic ranking");
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
     constexpr uint32_t TILE = Cfg::TILE;
@@ -791,32 +807,68 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     const bool hi_word = KW == 2 && shift_full >= 32u;
     static_assert(THREADS >= 256 && THREADS % 64 == 0, "need >= 256 threads");
     static_assert(KPT % 4 == 0 && TILE <= 65536, "offsets are packed 2 x 16 bit, digits 4 x 8 bit");
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[Cfg::LDS_BYTES];
+    static_assert(POS == 0 || PERSIST, "the position-chain forms keep state across their tiles");
     uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_raw);
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_raw + Cfg::STAGE_BYTES);
     uint32_t* s_dpre = s_whist + WAVES * RADIX;  // tile-local exclusive digit prefix
     uint32_t* s_gbase = s_dpre + RADIX;          // global base of digit run minus s_dpre
     uint32_t* s_misc = s_gbase + RADIX;          // [0] chain, [1] ticket (~0 = none), [4..7] wave totals of the digit scan,
                                                  // [9..14] the pass's flag/plan words
-
-    uint32_t* s_tcnt = s_misc + 16;              // counting pass: next-digit counts of the tile's heavy-value keys [0, 256)
-                                                 // and of the keys below it in its digit group [256, 512)
+    uint32_t* s_cnt = s_misc + 16;               // POS: [NCH][256] keys written to position segment x whose next digit is d
+    uint32_t* s_dstart = s_cnt + (POS == 1 ? NCH * RADIX : 0);  // POS: digit starts of this pass (from the counts of the pass before)
+    uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds >= n/8 keys, [2..3] (count << 8 | 255 - digit) max
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
-        constexpr uint32_t HWORDS = 4 * NCH * RADIX;
         const uint32_t i = blockIdx.x * THREADS + tid;
-        if (i < HWORDS / 4) reinterpret_cast<uint4*>(hsub - HWORDS)[i] = uint4{0u, 0u, 0u, 0u};
+        if (i < HIST_WORDS / 4) reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
     }
     if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
         const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
         if (skewed != ((mode & 16u) != 0u)) return;
     }
-    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
-    if constexpr (Cfg::HEAVY)
-        for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_tcnt[i] = 0;
+    // ---- POS: what a workgroup of a position-chain pass sets up once.  Behind the first pass nobody knows the pass's digit
+    // counts upfront: CNEXT[this pass][segment][digit], gathered by the pass that wrote this pass's input, is all there
+    // is — every workgroup derives the digit starts (s_dstart), whether the pass is skewed and its most frequent digit
+    // from it (16 coalesced loads per digit thread); tile 0 of each chain turns it into the chain's row 0.
+    bool pos_derived = false, pos_skew = false;  // uniform
+    uint32_t pos_mode = 0xffffffffu, cnt_guess = 0xffffffffu;
+    const uint32_t* cn_in = hsub + (shift_full >> 3) * HSUB_STRIDE;
+    if constexpr (POS != 0) {
+        if constexpr (POS == 1)
+            for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) s_cnt[i] = 0;
+        pos_derived = shift_full != 0u;  // (the first pass of a PF_POS sort is never dropped: its chains come from the Scan kernel)
+        if (pos_derived) {
+            uint32_t G = 0, incl = 0;
+            if (tid < 4) s_pos[tid] = 0;
+            if (tid < RADIX) {
+#pragma unroll
+                for (uint32_t x = 0; x < NCH; ++x) G += cn_in[x * RADIX + tid];
+                incl = wave_inclusive_scan_dpp(G);
+                if (lane == 63) s_misc[4 + wave] = incl;
+            }
+            __syncthreads();
+            if (tid < RADIX) {
+                uint32_t wbase = 0;
+                for (uint32_t w = 0; w < wave; ++w) wbase += s_misc[4 + w];
+                s_dstart[tid] = wbase + incl - G;
+                if (G >= (n >> 3) + 1u) {
+                    s_pos[0] = 1u;
+                    atomicMax(reinterpret_cast<unsigned long long*>(s_pos + 2), ((unsigned long long)G << 8) | (255u - tid));
+                }
+            }
+            __syncthreads();
+            pos_skew = uni(s_pos[0]) != 0u;
+            pos_mode = pos_skew ? 255u - (uni(s_pos[2]) & 255u) : 0xffffffffu;
+        }
+    }
     GS_TRACE_SETUP();
+#pragma unroll 1
+    for (;;) {  // PERSIST: one tile after the other until every chain is claimed; otherwise ONE tile per workgroup
+    if constexpr (PERSIST) __syncthreads();  // the last tile's readers of the stage and of s_misc are through
+    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
     GS_TRACE(0);
     // ---- claim a tile.  Fast path: ONE returning atomic on the ticket counter of
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
@@ -835,15 +887,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     // from the upfront histograms no longer bound this pass's writes — do nothing.  Read by another wave, in
     // flight together with the ticket atomic, so it adds no latency.  Same for the pass's flag and plan words.
     if (tid == 64) s_misc[3] = ld_agent(status);
-    if (tid >= 128 && tid < 135) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, cnt_h, cnt_start, cnt_sublen, xh, mode
+    if (tid >= 128 && tid < 135) s_misc[9 + (tid - 128)] = info[PASS_FLAGS + (tid - 128)];  // flags, nch, next_shift, seglog, -, -, mode
     __syncthreads();
     // Everything below that is the same for the whole workgroup is made SCALAR explicitly (values read from LDS
     // or through a VGPR index are vector registers to the compiler: pointers selected by them cost two VGPRs
     // each and a 64-bit vector add per access, and every branch on them is an exec-mask branch).
-    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    if (uni(s_misc[3]) != STATUS_OK) return;
-    const uint32_t pflags = uni(s_misc[9]);
-    if ((mode & 2u) && (pflags & PF_SKIP)) return;  // identity pass of a full sort
+    if (uni(s_misc[3]) != STATUS_OK) break;
+    const uint32_t pflags = uni(s_misc[9]) | (pos_skew ? PF_SKEW : 0u);
+    if ((mode & 2u) && (pflags & PF_SKIP)) break;  // identity pass of a full sort
 #ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with GPUSORT_SKIP_PASSES=0)
     const bool swapped = false;
 #else
@@ -854,9 +905,9 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     const void* vals_in_ = swapped ? vals_b : vals_a;
     void* vals_out_ = swapped ? vals_a : vals_b;
     const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
-    const uint32_t nch = uni(s_misc[10]);                                 // chains of this pass (NCH or MAXCH)
-    const uint32_t cnt_h = (Cfg::HEAVY && (mode & 2u)) ? uni(s_misc[11]) : 0xffffffffu;  // heavy value this pass counts for the next one
-    const uint32_t cnt_start = uni(s_misc[12]), cnt_sublen = uni(s_misc[13]);
+    const uint32_t nch = uni(s_misc[10]);                                 // chains of this pass
+    // POS: bit position of the next running pass's digit (~0: nothing to count) and log2 of its position segments
+    const uint32_t next_shift = (POS == 1 && (mode & 2u)) ? uni(s_misc[11]) : 0xffffffffu, seglog = uni(s_misc[12]);
     uint32_t tile = uni(s_misc[1]);
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
@@ -907,7 +958,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
         __syncthreads();
         chain = uni(s_misc[0]);
         tile = uni(s_misc[1]);
-        if (tile == 0xffffffffu) return;  // every chain is fully claimed
+        if (tile == 0xffffffffu) break;  // every chain is fully claimed
         seg_start = uni(info[I_START + chain]);
         seg_end = uni(info[I_END + chain]);
         row0 = uni(info[I_ROW + chain]);
@@ -919,18 +970,14 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     const uint32_t head = lo - tile_base;  // masked keys in front (first tile of a chain only)
     const bool full = (count == TILE);
     uint32_t* cdesc = desc + (size_t)row0 * RADIX;  // row 0 of this chain
-    // Heavy layout: the slices of the heavy value's run (chains < NCH) and the digits above it (chain 2*NCH)
-    // start where the counts gathered by the PREVIOUS pass say — tile 0 of such a chain seeds its row 0 now,
-    // long before a successor can walk that far: seed of the heavy group's chain (set by scan_kernel)
-    // + keys of that group below the heavy value + the slices in front of this one.
-    if (GS_UNLIKELY(Cfg::HEAVY && (pflags & PF_HEAVY) && tile == 0u && (chain < NCH || chain == 2 * NCH) && tid < RADIX)) {
-        const uint32_t* hs = hsub + (shift >> 3) * HSUB_STRIDE;
-        const uint32_t grp_chain = NCH + uni(s_misc[14]);
-        uint32_t seed = ld_agent(&desc[(size_t)info[I_ROW + grp_chain] * RADIX + tid]) >> 2;
-        seed += hs[NCH * RADIX + tid];
-        const uint32_t in_front = chain < NCH ? chain : NCH;
-        for (uint32_t s = 0; s < in_front; ++s) seed += hs[s * RADIX + tid];
-        st_agent(&cdesc[tid], (seed << 2) | FLAG_INCLUSIVE);
+    // POS behind the first pass: tile 0 of a chain seeds the chain's row 0 — the digit's start plus the chains in front — long
+    // before a successor can walk that far (a walk that gets there first polls the zero word like any row not yet there)
+    if constexpr (POS != 0) {
+        if (GS_UNLIKELY(pos_derived && tile == 0u && tid < RADIX)) {
+            uint32_t seed = s_dstart[tid];
+            for (uint32_t x = 0; x < chain; ++x) seed += cn_in[x * RADIX + tid];
+            st_agent(&cdesc[tid], (seed << 2) | FLAG_INCLUSIVE);
+        }
     }
     GS_TRACE(1);
     uint32_t early_row = 0;
@@ -1064,7 +1111,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             // 2.4 us for uniform keys, profiles/r02_skew_rank_fixed_mode.txt.)
             constexpr int SKEW_CHUNK = KPT % 8 == 0 ? 8 : 4;
             static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
-            const uint32_t sd = uni(s_misc[15]);
+            const uint32_t sd = pos_derived ? pos_mode : uni(s_misc[15]);
             uint32_t run = 0;  // wave-uniform: keys of digit sd in this wave so far
 #pragma unroll
             for (int c = 0; c < KPT; c += SKEW_CHUNK) {
@@ -1084,33 +1131,6 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
                 }
             }
             if (lane == 0 && sd < RADIX) whist[sd] = run;
-        }
-        if (pflags & PF_SKEW) {
-            // Counting pass (a heavy value implies a skewed pass): next-digit counts of the tile's heavy-value
-            // keys.  A loop of its own — inside the ranking loop its non-returning adds made the compiler wait
-            // for every ranking atomic (+0.17 ms per pass).  Every thread keeps the count of its own most
-            // frequent next digit (the first it meets) in a register; only the other keys cost an LDS add.
-            if (cnt_h != 0xffffffffu && !GS_ABL_NO_HEAVY_COUNT) {  // uniform
-                uint32_t cnt_mine = 0xffffffffu, cnt_l0 = 0;
-                const uint32_t grp_lo = cnt_h & ~(RADIX / NCH - 1u);
-                // straight-line selects and ONE predicated add per key (the branchy form cost 45 instructions
-                // and 8 scalar branches per key: +0.17 ms per pass; a wave-level form on the scalar unit — ballots,
-                // s_bcnt1, a uniform branch per key — was slower too: 0.68 vs 0.63 ms)
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    const uint32_t d = (key[i] >> shift) & 255u;
-                    const uint32_t dn = (key[i] >> (shift + 8u)) & 255u;
-                    const uint32_t idx = my_base + i * 64u;
-                    const bool valid = full || (idx >= lo && idx < hi);
-                    const bool is_h = valid && d == cnt_h;
-                    const bool is_a = valid && d < cnt_h && d >= grp_lo;
-                    const bool match = is_h && (dn == cnt_mine || cnt_mine == 0xffffffffu);
-                    cnt_mine = match ? dn : cnt_mine;
-                    cnt_l0 += match ? 1u : 0u;
-                    if ((is_h && !match) || is_a) atomicAdd(&s_tcnt[(is_a ? RADIX : 0u) + dn], 1u);
-                }
-                if (cnt_l0) atomicAdd(&s_tcnt[cnt_mine], cnt_l0);
-            }
         }
     }
     GS_TRACE(2);
@@ -1230,7 +1250,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             if (stalled) {
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
-                if (GS_FALLBACK && k > 0 && spins > FALLBACK_SPINS) {  // (row 0 of a heavy-layout chain is seeded by its tile 0)
+                if (GS_FALLBACK && k > 0 && spins > FALLBACK_SPINS) {  // (row 0 of a PF_POS chain behind the first pass is seeded by its tile 0)
                     atomicMax(&s_misc[8], (uint32_t)k);  // ask the workgroup to recount tile k-1
                     return;
                 }
@@ -1303,7 +1323,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
     }
     GS_TRACE(5);
     GS_TRACE_END(chain);
-    if (uni(s_misc[2]) != 0u) return;  // look-back gave up (timeout or poisoned predecessor): write nothing
+    if (uni(s_misc[2]) != 0u) break;  // look-back gave up (timeout or poisoned predecessor): write nothing
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----
@@ -1321,31 +1341,32 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
         }
     }
 
-    // ---- counting pass (heavy value cnt_h of THIS digit): the next pass splits the value's run into NCH
-    // position slices and needs, per slice, the counts of its own digit.  The tile's totals were gathered
-    // while ranking (s_tcnt); now that the run's output position is known they go to the slice it falls
-    // into.  A tile's run is at most one tile long and a slice is at least one, so the run touches at most
-    // two slices — the few tiles per pass whose run crosses a slice boundary recount it by position.
-    uint32_t* s_cnt = s_whist + RADIX;  // recount: 2 x 256 words; the per-wave counters are dead, [0, 256) is the fallback's
-    uint32_t cnt_first = 0;
-    bool cnt_split = false;
-    if (GS_UNLIKELY(cnt_h != 0xffffffffu)) {  // uniform
-        const uint32_t o_first = s_gbase[cnt_h] + s_dpre[cnt_h] + (cnt_h == 0u ? head : 0u);
-        const uint32_t run_end = s_gbase[cnt_h] + (cnt_h == 255u ? head + count : s_dpre[cnt_h + 1u]);  // one past the run's last key
-        cnt_first = (o_first - cnt_start) / cnt_sublen;
-        const uint32_t boundary = cnt_start + (cnt_first + 1u) * cnt_sublen;
-        cnt_split = run_end > boundary;
-        if (cnt_split) {
-            for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) s_cnt[i] = 0;
-            __syncthreads();
-            const uint32_t gb_h = s_gbase[cnt_h];
-#pragma unroll 4
-            for (int j = 0; j < KPT; ++j) {
-                const uint32_t i = tid + j * THREADS;
-                const uint32_t kb = s_stage[i];
-                if ((full || (i >= head && i < head + count)) && ((kb >> shift) & 255u) == cnt_h)
-                    atomicAdd(&s_cnt[(gb_h + i >= boundary ? RADIX : 0u) + ((kb >> (shift + 8u)) & 255u)], 1u);
-            }
+    // ---- POS: count the next pass's digit per output position segment while scattering.  One LDS add per key on the
+    // workgroup's table [segment][digit] (flushed once, when the workgroup runs out of tiles); the stage is ordered by
+    // THIS digit, so the lanes of one scatter instruction write one or two runs — one segment, with few exceptions — and
+    // their next digits are what collides: the lanes holding the wave's guess of the most frequent next digit are counted
+    // with ONE add of their popcount by the first of them, everybody else adds 1 (plain adds cost 0.23 / 0.57 ms per pass
+    // at entropy presets 3 / 5 against 0.01 ms for uniform keys, profiles/r03_next_digit_count_cost.txt).
+    auto count_next = [&](uint32_t kb, uint32_t o, bool valid) {
+        const uint32_t dn = (kb >> (next_shift & 31u)) & 255u;
+        const uint32_t bin = ((o >> seglog) << 8) + dn;
+        const bool hot = valid && dn == cnt_guess;
+        const unsigned long long H = __builtin_amdgcn_ballot_w64(hot);
+        uint32_t add = valid ? 1u : 0u;
+        if (H) {  // uniform
+            const uint32_t first = (uint32_t)__builtin_ctzll(H);
+            const uint32_t bin_first = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)first);
+            if (__builtin_amdgcn_ballot_w64(hot && bin != bin_first) == 0ull)  // one segment: one add for all of them
+                add = hot ? (lane == first ? (uint32_t)__popcll(H) : 0u) : add;
+        }
+        if (add) atomicAdd(&s_cnt[bin], add);
+    };
+    const bool counting = POS == 1 && next_shift != 0xffffffffu;  // uniform
+    if constexpr (POS == 1) {
+        if (counting) {  // the wave's guess: the first lane's next digit, if at least 8 lanes of the first 64 slots share it
+            const uint32_t k0 = s_stage[wave * 64u + lane];
+            const uint32_t d0 = (k0 >> (next_shift & 31u)) & 255u, c0 = uni(d0);
+            if (__popcll(__builtin_amdgcn_ballot_w64(d0 == c0)) >= 8) cnt_guess = c0;
         }
     }
 
@@ -1418,8 +1439,10 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const uint32_t d = (kb[j] >> shift) & 255u;
-                st_stream(keys_out + (((s_gbase[d] + tid + j * THREADS) ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
-                GS_ABL_COUNT_NEXT(kb[j], s_gbase[d] + tid + j * THREADS);
+                const uint32_t opos = s_gbase[d] + tid + j * THREADS;
+                st_stream(keys_out + ((opos ^ rev_xor) + rev_add), from_bits<KT>(kb[j]));
+                GS_ABL_COUNT_NEXT(kb[j], opos);
+                if constexpr (POS == 1) { if (counting) count_next(kb[j], opos, true); }
                 if constexpr (VB != 0) digs[j >> 2] |= d << (8 * (j & 3));
             }
         }
@@ -1432,6 +1455,7 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             const uint32_t kb = KW == 2 ? kb2.x : s_stage[i];
             const uint32_t d = (kb >> shift) & 255u;
             uint32_t o = s_gbase[d] + i;
+            if constexpr (POS == 1) { if (counting) count_next(kb, o, full || (i >= head && i < head + count)); }
             if (reverse) o = n - 1u - o;
             GS_ABL_OUT_INDEX(o, i);
             if (full || (i >= head && i < head + count)) {
@@ -1495,22 +1519,51 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
             }
         }
     }
-    if (GS_UNLIKELY(cnt_h != 0xffffffffu && !GS_ABL_NO_HEAVY_FLUSH)) {  // hand the tile's counts to the next pass
-        uint32_t* hs = hsub + ((shift >> 3) + 1u) * HSUB_STRIDE;
-        if (cnt_split) __syncthreads();  // the recount is complete
-        for (uint32_t i = tid; i < 2 * RADIX; i += THREADS) {
-            if (i >= RADIX) {  // keys of the heavy value's digit group below it
-                const uint32_t v = s_tcnt[i];
-                if (v != 0u) atomicAdd(&hs[NCH * RADIX + (i - RADIX)], v);
-            } else if (!cnt_split) {
-                const uint32_t v = s_tcnt[i];
-                if (v != 0u && cnt_first < NCH) atomicAdd(&hs[cnt_first * RADIX + i], v);
-            } else {
-                const uint32_t v0 = s_cnt[i], v1 = s_cnt[RADIX + i];
-                if (v0 != 0u && cnt_first < NCH) atomicAdd(&hs[cnt_first * RADIX + i], v0);
-                if (v1 != 0u && cnt_first + 1u < NCH) atomicAdd(&hs[(cnt_first + 1u) * RADIX + i], v1);
+    if constexpr (!PERSIST) break;
+    }  // tiles
+    if constexpr (POS == 1) {
+        // hand the counts to the next pass that runs: CNEXT[that pass][segment][digit] += this workgroup's table
+        const uint32_t ns = uni(info[I_NEXT_SHIFT]);
+        if ((mode & 2u) && ns != 0xffffffffu) {
+            __syncthreads();
+            uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
+            for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
+                const uint32_t v = s_cnt[i];
+                if (v != 0u) atomicAdd(&cn_out[i], v);
             }
         }
+    }
+}
+
+// One workgroup per tile: every key / value type, every compiled shape.
+template <int THREADS, int KPT, int VB, int KT, int RANK, int VR = 1>
+__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::WAVES_PER_SIMD)) void digit_binning_kernel(
+    uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
+    uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::LDS_BYTES];
+    binning_body<THREADS, KPT, VB, KT, RANK, VR, 0, false>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n,
+                                                           shift_full, mode);
+}
+
+// Keys-only sorts of 32-bit keys that the Scan kernel MAY plan on position chains (PF_POS, decided on the device from what the
+// histogram kernel saw): ONE launch per pass serves both plans — persistent workgroups, two per CU, that run the plain form of
+// the pass (512 x 32 tiles, chains as planned) or, under PF_POS, its position-chain form: 512 x 24 tiles and the next-digit
+// table while a later pass needs the counts (LAST = false), 512 x 32 tiles without it in the last pass (LAST = true).  (As two
+// launches per pass, one of them exiting on the flag, every pass paid a second kernel boundary: +0.01 ms, profiles/r03_pos_*.)
+template <int KT, bool LAST>
+__global__ __launch_bounds__(512, 4) void digit_binning_dual_kernel(
+    uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
+    uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
+    constexpr int LDS_PLAIN = BinCfg<512, 32, 0, 1, 1, 0>::LDS_BYTES;
+    constexpr int LDS_POS = LAST ? BinCfg<512, 32, 0, 1, 1, 2>::LDS_BYTES : BinCfg<512, 24, 0, 1, 1, 1>::LDS_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_PLAIN > LDS_POS ? LDS_PLAIN : LDS_POS];
+    static_assert(sizeof(s_raw) * 2 <= 160 * 1024, "two workgroups per CU");
+    if ((__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) == 0) {
+        binning_body<512, 32, 0, KT, 1, 1, 0, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
+    } else if constexpr (LAST) {
+        binning_body<512, 32, 0, KT, 1, 1, 2, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
+    } else {
+        binning_body<512, 24, 0, KT, 1, 1, 1, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
     }
 }
 
@@ -1524,17 +1577,19 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
 // [3] non-zero HIST words, [4 + pass] keys accounted for by the pass's descriptors.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, uint32_t desc_stride, uint32_t tile_keys,
-                                                           uint32_t p0, uint32_t dyn, unsigned long long* report) {
+                                                           uint32_t p0, uint32_t dyn, unsigned long long* report,
+                                                           uint32_t tile_keys_pos /*tile of a sort planned with PF_POS*/) {
     const uint32_t tid = threadIdx.x, q = blockIdx.y, chain = blockIdx.x;
     if (q == 0 && chain == 0) {
         uint32_t nz = 0;
-        for (uint32_t i = tid; i < 4 * NCH * RADIX; i += 256) nz += slab[SLAB_HIST + i] != 0u;
+        for (uint32_t i = tid; i < HIST_WORDS; i += 256) nz += slab[SLAB_HIST + i] != 0u;
         if (nz) atomicAdd(&report[3], (unsigned long long)nz);
     }
     const uint32_t* info = slab + SLAB_INFO + q * INFO_STRIDE;
     if (dyn && (info[PASS_FLAGS] & PF_SKIP)) return;  // an identity pass that was dropped: nothing ran
     if (chain >= info[I_NCH]) return;
-    const uint32_t tiles = chain_tiles(info[I_START + chain], info[I_END + chain], tile_keys);
+    const uint32_t tiles = chain_tiles(info[I_START + chain], info[I_END + chain],
+                                       ((info[PASS_FLAGS] & PF_POS) && q != 3u) ? tile_keys_pos : tile_keys);
     if (tiles == 0) return;
     const uint32_t* rows = slab + SLAB_DESC + (size_t)q * desc_stride + (size_t)info[I_ROW + chain] * RADIX;
     if (tid == 0 && slab[SLAB_COUNTERS + ((p0 + q) * COUNTERS_PER_PASS + chain) * COUNTER_STRIDE] < tiles)

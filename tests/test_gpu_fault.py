@@ -22,7 +22,7 @@ def _run(lib, code):
     path = os.path.join(LIBDIR, lib)
     if not os.path.exists(path):
         pytest.fail(f"{lib} missing: run __graft_entry__.build()")
-    env = dict(os.environ, GPUSORT_LIB=path, GPUSORT_HEAVY_MIN_LOG2="22")  # heavy-value layout already at 2^23 keys
+    env = dict(os.environ, GPUSORT_LIB=path, GPUSORT_POS_MIN_LOG2="22")  # position-chain plan for skewed keys already at 2^22 keys
     out = subprocess.run([sys.executable, "-c", textwrap.dedent(code) % ROOT], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -34,8 +34,8 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
         import sys, time, torch
         sys.path.insert(0, %r)
         import gpusorting_amd as g
-        # tile 5 of chain 3 stays silent in every pass; the third case is skewed enough (entropy preset 5) for the
-        # heavy-value layout, where chain 3 is a position slice whose row 0 its tile 0 seeds itself
+        # tile 5 of chain 3 stays silent in every pass; the third case is skewed (entropy preset 5): the position-chain
+        # plan, where behind the first pass every chain's row 0 is seeded by its tile 0
         for n, pairs, preset in ((1 << 22, False, 0), ((1 << 22) + 12345, True, 0), ((1 << 23) + 777, False, 4)):
             k = torch.empty(n, dtype=torch.int32, device="cuda")
             g.init_random(k, 10, preset)

@@ -27,13 +27,20 @@ def to_host(t, dtype):
     return t.cpu().numpy().view(dtype)
 
 
-@pytest.fixture(autouse=True, params=["default-routing", "general-path"])
+@pytest.fixture(autouse=True, params=["default-routing", "general-path", "position-chains"])
 def routing(request, monkeypatch):
-    """Every test of this file runs twice: with the library's own routing (single-tile kernel for small n, the
-    two-launch MSD + bucket sort up to 2^20 keys, the six-launch pipeline above) and with the mid-size route
-    switched off, so that the general pipeline stays covered at the sizes the mid-size route now takes."""
+    """Every test of this file runs three times: with the library's own routing (single-tile kernel for small n, the
+    two-launch MSD + bucket sort up to 2^20 keys, the six-launch pipeline above); with the mid-size route
+    switched off, so that the general pipeline stays covered at the sizes the mid-size route now takes; and with
+    every keys-only sort of 2^20 32-bit keys or more forced onto the position-chain plan (PF_POS: all four passes on
+    position chains, each counting the next one's digit while it scatters — the plan skewed keys get at 2^25 keys and
+    more), whatever the keys look like."""
     if request.param == "general-path":
         monkeypatch.setenv("GPUSORT_MID_PATH", "0")
+    if request.param == "position-chains":
+        monkeypatch.setenv("GPUSORT_MID_PATH", "0")
+        monkeypatch.setenv("GPUSORT_POS", "2")
+        monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "20")
     return request.param
 
 
@@ -535,9 +542,13 @@ def test_identity_passes_dropped_on_device(gpu, oracle, P, skip, vb, kt, order):
         s.close()
 
 
-def test_dropped_passes_cost_nothing(gpu):
-    """16-bit keys: passes 2 and 3 must be launches of workgroups that exit at once."""
+def test_dropped_passes_cost_nothing(gpu, routing):
+    """16-bit keys: passes 2 and 3 must be launches of workgroups that exit at once.  (Constant bytes do not count as
+    skew — the default routing keeps such keys on the plan that drops their passes; FORCED onto position chains, whose
+    passes learn their digit counts only from the pass before, all four passes run.)"""
     import torch
+    if routing == "position-chains":
+        pytest.skip("the forced position-chain plan never drops a pass")
     n = 1 << 24
     k = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device="cuda")
     s = gpu.OneSweep(n)
@@ -573,11 +584,13 @@ def _heavy_inputs(oracle, n):
 
 
 @pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (4, 0, 0), (8, 0, 1), (0, 1, 1), (4, 2, 0)])
-def test_heavy_value_position_slices(gpu, oracle, vb, kt, order, monkeypatch):
-    """A digit value holding more than half of the keys: the next pass splits its run into position slices whose
-    bases come from counts gathered by the pass before.  The library switches that layout on from 2^26 keys
-    (where it pays); GPUSORT_HEAVY_MIN_LOG2 lowers the threshold to the kernel's floor for this test."""
-    monkeypatch.setenv("GPUSORT_HEAVY_MIN_LOG2", "22")
+def test_skewed_keys_take_position_chains(gpu, oracle, vb, kt, order, monkeypatch, routing):
+    """Skewed keys (uneven digit groups): the histogram kernel notices, the Scan kernel plans every pass on position
+    chains, each pass counts the next one's digit per output segment while it scatters.  The library allows that plan
+    from 2^25 keys up; GPUSORT_POS_MIN_LOG2 lowers the threshold for this test (keys-only sorts; the pairs cases run
+    the digit-group chains on the same inputs)."""
+    if routing != "position-chains":
+        monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "22")
     n = (1 << 22) + 54321
     for name, keys in _heavy_inputs(oracle, n):
         vals = None if not vb else np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
@@ -618,11 +631,11 @@ def _fuzz_keys(rng, oracle, n):
     return (u >> np.uint32(int(rng.integers(0, 31)))).astype(np.uint32)
 
 
-def test_fuzz_against_oracle(gpu, oracle, monkeypatch):
-    """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, heavy layout —
-    its size threshold lowered to the kernel's floor), distributions, key types, orders and value widths;
+def test_fuzz_against_oracle(gpu, oracle, monkeypatch, routing):
+    """Seeded random sweep over sizes (1 .. 6M, so every path: single tile, 8192-key tiles, position-chain plan —
+    its size threshold lowered), distributions, key types, orders and value widths;
     every case bit-exact against the oracle."""
-    monkeypatch.setenv("GPUSORT_HEAVY_MIN_LOG2", "22")
+    monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "21")
     rng = np.random.default_rng(int(os.environ.get("GPUSORT_FUZZ_SEED", "20260925")))
     for case in range(int(os.environ.get("GPUSORT_FUZZ_CASES", "48"))):  # longer hunts: set the two variables
         top = (40000, 300000, 6 << 20)[case % 3]
