@@ -49,9 +49,9 @@ _PROTOS = [
     ("gs_onesweep_set_skip_passes", _int, [_vp, _int]),
     ("gs_onesweep_set_mid_path", _int, [_vp, _int]),
     ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
-    ("gs_debug_copy_floor", _int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     ("gs_debug_set_trace", _int, [_vp, _vp]),
     ("gs_debug_check_state", _int, [_vp, C.POINTER(C.c_uint64), _vp]),
+    ("gs_debug_poke_status", _int, [_vp, _u32, _vp]),
     ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
     ("gs_onesweep_msd_prepare", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
@@ -113,6 +113,18 @@ def load() -> C.CDLL:
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def load_tuning() -> C.CDLL:
+    """libgpusort_tuning.so (-DGS_TUNING: calibration kernels and tuning tile shapes; tools/ and bench.py's box_floor block —
+    never the product path)."""
+    path = os.path.join(_HERE, "lib", "libgpusort_tuning.so")
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    lib.gs_debug_copy_floor.restype = _int
+    lib.gs_debug_copy_floor.argtypes = [_vp, _vp, _u32, _u32, _u32, _vp]
+    return lib
 
 
 def check(status: int, where: str) -> None:

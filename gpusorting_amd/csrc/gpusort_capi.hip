@@ -109,14 +109,18 @@ struct Shape {
 #ifdef GS_MINIMAL
 #define GS_ROWS_KEYS64(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}}
 #define GS_KEYSONLY64(T, K) {T, K, {GS_ROWS_KEYS64(T, K, 0), GS_ROWS_KEYS64(T, K, 1)}}
-const Shape g_shapes[] = {GS_KEYSONLY64(512, 32), GS_KEYSONLY64(1024, 16), GS_KEYSONLY64(512, 16)};
+const Shape g_shapes[] = {GS_KEYSONLY64(512, 32), GS_KEYSONLY64(1024, 16), GS_KEYSONLY64(512, 16),
+#ifdef GS_TUNING
+                          GS_KEYSONLY64(256, 32), GS_KEYSONLY64(256, 16), GS_KEYSONLY64(512, 20),
+#endif
+};
 #else
 const Shape g_shapes[] = {
     GS_FULL(512, 32),   // default for keys-only and 8-byte values: 16384-key tiles, 2 workgroups per CU
     GS_FULL(1024, 16),  // default for 4-byte values (measured best, profiles/r01_sweep_v16_*)
     GS_FULL64(512, 16), // mid sizes (n <= mid_keys): 8192-key tiles, shorter per-tile latency, more workgroups;
                         // and the shape of 64-bit keys at every size (8-byte stage slots: 64 KiB per tile)
-#ifndef GS_NO_TUNING_SHAPES
+#ifdef GS_TUNING  // tuning build only (libgpusort_tuning.so)
     GS_U32ONLY(256, 32), GS_U32ONLY(256, 16),
     GS_U32ONLY(512, 20),  // 10 240-key tiles: 52 KiB of LDS, three workgroups per CU
 #endif
@@ -245,18 +249,20 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
     // between left it dirty: zero it here, once, instead of double counting silently.
     if (h->hist_dirty) GS_HIP(zero_hist(h, s));
-    if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
-    if (h->profiling) GS_HIP(hipEventRecord(h->ev[1], s));
+    // (64-bit keys: the second round's kernels are charged to slot 6 — its events stay where round 0 put them)
+    const bool rec = h->profiling && word == 0;
+    if (rec) GS_HIP(hipEventRecord(h->ev[0], s));
+    if (rec) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
                (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
-    if (h->profiling) GS_HIP(hipEventRecord(h->ev[2], s));
+    if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
     hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
                        h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
-    if (h->profiling) GS_HIP(hipEventRecord(h->ev[3], s));
+    if (rec) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->desc_stride = desc_stride;
     h->last_n = n; h->last_tile = tile; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u;
@@ -273,10 +279,10 @@ gs_status check_common(gs_onesweep* h, const void* a, const void* b, uint32_t n,
 
 // single-tile fast path: one launch, no scan state.  Three tile sizes: 8192 slots (every mode), 16384
 // (keys-only and 4-byte values), 32768 (keys-only) — what fits 160 KiB of LDS.
-using SmallLauncher = void (*)(hipStream_t, uint32_t*, void*, uint32_t, uint32_t);
+using SmallLauncher = void (*)(hipStream_t, uint32_t*, void*, uint32_t, uint32_t, uint32_t*);
 template <int T, int K, int VB, int KT, int RANK>
-void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_t descending) {
-    hipLaunchKernelGGL((gs::small_sort_kernel<T, K, VB, KT, RANK>), dim3(1), dim3(T), 0, s, keys, vals, n, descending);
+void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_t descending, uint32_t* status) {
+    hipLaunchKernelGGL((gs::small_sort_kernel<T, K, VB, KT, RANK>), dim3(1), dim3(T), 0, s, keys, vals, n, descending, status);
 }
 #define GS_SMALL_ROW(T, K, VB, R) {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>, nullptr, nullptr, nullptr}
 #define GS_SMALL_ROW64(T, K, VB, R)                                                                                   \
@@ -312,8 +318,8 @@ void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, vo
                 uint32_t n, uint32_t descending) {
     hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK, T, K>), dim3(tiles), dim3(T), 0, s, keys, alt, vals, valt, scratch, status, n,
                        descending);
-    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T, K>), dim3(gs::RADIX), dim3(T), 0, s, keys, alt, vals, valt, scratch, n,
-                       descending);
+    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T, K>), dim3(gs::RADIX), dim3(T), 0, s, keys, alt, vals, valt, scratch, status,
+                       n, descending);
 }
 #ifndef GS_MINIMAL
 #define GS_MID_ROW(VB, R, T, K) {launch_mid<VB, 0, R, T, K>, launch_mid<VB, 1, R, T, K>, launch_mid<VB, 2, R, T, K>}
@@ -347,14 +353,13 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
 #endif
     if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
-        small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u);
+        small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u, h->slab + SLAB_STATUS);
         h->last_tile = 0;
         if (h->profiling)  // everything is charged to slot 0 (and the total)
             for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
         GS_HIP(hipGetLastError());
         h->profile_pending = h->profiling != 0;
-        // the scan state is untouched, so a later gs_onesweep_check() still reads the last tiled sort's word;
-        // the single-tile kernel has no spin and cannot time out
+        // the single-tile kernel has no spin and cannot time out: it sets the status word to OK
         return GS_OK;
     }
 #ifndef GS_MINIMAL
@@ -438,6 +443,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
 }  // namespace
 
 extern "C" gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
+#ifdef GS_TUNING
+extern "C" gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads, uint32_t kpt, void* stream);
+#endif
 
 namespace {
 bool lds_atomic_order_ok() {
@@ -625,13 +633,17 @@ gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* 
     return ret;
 }
 
+#ifdef GS_TUNING
+// Tuning aid: global access pattern of a DigitBinningPass without ranking or look-back (memory floor of the tile shape);
+// threads == 0: plain streaming copies (kpt 0 / 1 / 2 = default / nt loads / nt loads and stores) and a read-only sweep (kpt 3).
 gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads, uint32_t kpt, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t tiles = threads ? n / (threads * (kpt ? kpt : 1u)) : 1u;
     if (!tiles) return GS_ERR_SIZE;
     const uint32_t* in = static_cast<const uint32_t*>(d_in);
     uint32_t* out = static_cast<uint32_t*>(d_out);
-    if (threads == 512 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<512, 16>), dim3(tiles), dim3(512), 0, s, in, out, n);
+    if (threads == 512 && kpt == 32) hipLaunchKernelGGL((gs::copy_floor_kernel<512, 32>), dim3(tiles), dim3(512), 0, s, in, out, n);
+    else if (threads == 512 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<512, 16>), dim3(tiles), dim3(512), 0, s, in, out, n);
     else if (threads == 1024 && kpt == 16) hipLaunchKernelGGL((gs::copy_floor_kernel<1024, 16>), dim3(tiles), dim3(1024), 0, s, in, out, n);
     else if (threads == 256 && kpt == 32) hipLaunchKernelGGL((gs::copy_floor_kernel<256, 32>), dim3(tiles), dim3(256), 0, s, in, out, n);
     else if (threads == 0) {  // calibration copies: kpt = 0/1/2 copy policy, 3 = read-only sweep
@@ -646,6 +658,7 @@ gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
+#endif
 
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h) {
     return h ? (uint32_t)g_shapes[h->shape].threads * g_shapes[h->shape].kpt : 0;
@@ -686,6 +699,15 @@ gs_status gs_debug_read_status_words(gs_onesweep* h, uint32_t out[32], void* str
     return GS_OK;
 }
 #endif
+
+gs_status gs_debug_poke_status(gs_onesweep* h, uint32_t word, void* stream) {  // tests: forge the device status word
+    if (!h) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    h->pinned[0] = word;
+    GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS, h->pinned, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    GS_HIP(hipStreamSynchronize(s));
+    return GS_OK;
+}
 
 gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream) {
     if (!h || !report) return GS_ERR_ARG;

@@ -267,12 +267,16 @@ gs_status gs_mgpu_set_force_exchange(gs_mgpu* c, int on) {
 
 gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d_vals, uint32_t n, gs_key_type kt,
                                    void* d_out_keys, void* d_out_vals, uint32_t* out_n, void* stream) {
-    if (!c || !d_keys || !d_out_keys || !out_n || misaligned(d_keys) || misaligned(d_out_keys)) return GS_ERR_ARG;
+    // (an EMPTY shard may come with null input pointers — an empty tensor has none — and still takes part in every collective;
+    //  returning early here would leave the peers waiting in the all-gather)
+    if (!c || !d_out_keys || !out_n || misaligned(d_out_keys)) return GS_ERR_ARG;
+    if (n != 0 && (!d_keys || misaligned(d_keys))) return GS_ERR_ARG;
     if ((int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
     if (n > c->shard_keys) return GS_ERR_SIZE;
     const uint32_t vb = c->value_bytes;
     if (vb) {
-        if (!d_vals || !d_out_vals || misaligned(d_vals) || misaligned(d_out_vals)) return GS_ERR_ARG;
+        if (!d_out_vals || misaligned(d_out_vals)) return GS_ERR_ARG;
+        if (n != 0 && (!d_vals || misaligned(d_vals))) return GS_ERR_ARG;
     } else if (d_vals || d_out_vals) {
         return GS_ERR_MODE;
     }
@@ -385,6 +389,7 @@ gs_status gs_mgpu_get_profile(gs_mgpu* c, float ms[4], uint64_t* bytes_sent, uin
 gs_status gs_mgpu_last_plan(gs_mgpu* c, uint32_t* plan, uint32_t words) {
     if (!c || !plan || words < gs::plan_words(c->world)) return GS_ERR_ARG;
     memcpy(plan, c->h_plan, gs::plan_words(c->world) * sizeof(uint32_t));
+    plan[3] = c->last_fine;  // (no synchronisation: the plan is on the host since the call's one event wait)
     return GS_OK;
 }
 

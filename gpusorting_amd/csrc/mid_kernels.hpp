@@ -6,19 +6,30 @@
 // r01_size_and_entropy_sweep_v3.txt) — four global passes of >= 9 us each whatever the size.  At these sizes the keys
 // of one top-byte value fit ONE workgroup's LDS, so the sort is done as
 //   K1 mid_msd_kernel     one MSD pass: every workgroup (one tile each — 8192 keys, 16 384 above 2^20, 32 768 above 2^21 —
-//                         at most 128, all resident) ranks its
-//                         tile by the TOP byte, publishes its 256 counts, meets the others at ONE grid barrier, derives
-//                         every bucket's start and its own offsets from the count table, and scatters its tile into the
-//                         alt buffer (stable);
+//                         at most 128) ranks its tile by the TOP byte, publishes its 256 counts, waits until the count
+//                         table is complete, derives every bucket's start and its own offsets from it, and scatters its
+//                         tile into the alt buffer (stable);
 //   K2 bucket_sort_kernel one workgroup per top-byte bucket sorts it on the remaining 24 bits entirely in LDS (three
 //                         stable passes, as the single-tile sort) and writes it to its final place in the key buffer.
 // Two global passes instead of four (20 B/key instead of 36), two launches instead of six.  Same result as the LSD
 // sort: (stable by top byte) o (stable sort of each bucket by the low 24 bits) == stable sort by the whole key.
 // If a bucket would not fit a workgroup (skewed top byte) every workgroup sees that in the SAME count table and K1
-// runs the four LSD passes itself, with grid barriers between them (about the cost of the six-launch path, no
-// extra launch, no host decision); K2 then finds the route flag and exits.
-// Cross-workgroup data inside K1: the count table only — write-through (sc1) stores, drained, then the arrival
-// atomic; readers poll with sc1 loads and read the table with sc1 loads (MI355X_MICROARCH.md, valid forms).  On the
+// runs the four LSD passes itself, phase by phase (about the cost of the six-launch path, no extra launch, no host
+// decision); K2 then finds the route flag and exits.
+//
+// FORWARD PROGRESS WITHOUT RESIDENCY (round 3; reference: the look-back-with-fallback of SweepCommon.hlsl:297-425 and the
+// fault emulation of EmulatedDeadlocking.cu:36-37,159-267).  The wait for the count table is not a grid barrier: a tile
+// is WORK that a workgroup CLAIMS (atomicMax of the call's epoch on the tile's claim word), normally its own
+// (tile = blockIdx).  A workgroup that has waited ADOPT_SPINS polls for a tile's counts looks at the claim word: a tile
+// nobody has claimed — its workgroup has not been dispatched: another stream holds the CUs, the device is partitioned,
+// more tiles than resident workgroups — is claimed and processed by the waiter (counts now, scatter after its own).  A
+// workgroup that finally starts and finds its tile claimed exits.  Every wait is therefore for a tile whose owner is
+// RUNNING, whatever the occupancy; no timeout is needed for progress (the bounded spin stays as a last resort and
+// reports GS_ERR_TIMEOUT; K2 then writes nothing).  Nothing in the scratch region has to be cleared between calls: claim
+// words, row flags and the plan's epoch word carry the call's epoch — a DEVICE word (MID_CTR + 1) that the last workgroup of
+// K2 to finish advances, so that a captured HIP graph replays with fresh epochs.
+// Cross-workgroup data inside K1: the count table — write-through (sc1) stores, drained, then the row's flag word;
+// readers poll the flags with sc1 loads and read the table with sc1 loads (MI355X_MICROARCH.md, valid forms).  On the
 // LSD route the keys themselves cross workgroups between passes: written and read with sc1 accesses as well.
 #pragma once
 #include "onesweep_kernels.hpp"
@@ -32,14 +43,31 @@ namespace gs {
 constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // the smallest shape
 constexpr uint32_t MID_MAX_TILES = 128;
 constexpr uint32_t MID_MAX_KEYS = MID_MAX_TILES * MID_TILE;                            // 2^20: limit of the smallest shape
-// scratch words in the handle's slab (SLAB_MID: its own region, zero whenever no mid-size sort is in flight)
-constexpr uint32_t MID_ARRIVE = 0;                  // barrier counter: counts up during K1, K2 puts it back to zero
+// scratch words in the handle's slab (SLAB_MID)
+constexpr uint32_t MID_EPOCH = 0;                   // epoch of the call whose plan (route, bucket table) is below — K2's licence
+constexpr uint32_t MID_CTR = 8;                     // epoch of the last completed call (advanced by K2's last workgroup)
+constexpr uint32_t MID_DONE = 12;                   // K2 workgroups of the running call that have finished
+constexpr uint32_t MID_RESET = 16;                  // epoch of the call whose first workgroup has reset the status word
 constexpr uint32_t MID_ROUTE = 32;                  // 0 = MSD route (K2 sorts the buckets), 1 = K1 did the LSD passes
 constexpr uint32_t MID_BSTART = 64;                 // bucket starts [256]
 constexpr uint32_t MID_BCOUNT = MID_BSTART + RADIX; // bucket counts [256]
-constexpr uint32_t MID_TABLE = MID_BCOUNT + RADIX;  // two count tables [2][MID_MAX_TILES][256]
+constexpr uint32_t MID_CLAIM = MID_BCOUNT + RADIX;  // [128] epoch of the call in which the tile was claimed
+constexpr uint32_t MID_AFLAG = MID_CLAIM + MID_MAX_TILES;  // [128] tag of the tile's last published count row
+constexpr uint32_t MID_BFLAG = MID_AFLAG + MID_MAX_TILES;  // [128] tag of the tile's last finished scatter (LSD route)
+constexpr uint32_t MID_TABLE = 1024;                // two count tables [2][MID_MAX_TILES][256]
 constexpr uint32_t MID_WORDS = MID_TABLE + 2 * MID_MAX_TILES * RADIX;
+static_assert(MID_BFLAG + MID_MAX_TILES <= MID_TABLE, "mid scratch layout");
 static_assert(MID_WORDS <= SLAB_MID_WORDS, "SLAB_MID is too small");
+// a tag orders the phases of all calls on a handle: (epoch, step), step 0 = MSD counts, 1 + 2 p = counts of LSD pass p,
+// 2 + 2 p = its scatter; epoch < 2^26: K2's last workgroup then zeroes claim words and flags and restarts the count
+__host__ __device__ constexpr uint32_t mid_tag(uint32_t epoch, uint32_t step) { return epoch * 16u + step + 1u; }
+
+#ifndef GS_MID_ADOPT_SPINS
+#define GS_MID_ADOPT_SPINS 64u  // polls (~1-2 us each) on a missing count row before the waiter looks at the tile's claim word
+#endif
+#ifndef GS_FAULT_MID_ABSENT
+#define GS_FAULT_MID_ABSENT(block) false  // fault injection: this workgroup of K1 behaves as if it had never been dispatched
+#endif
 
 __device__ __forceinline__ uint32_t ld_sc1(const uint32_t* p) {
     return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -94,27 +122,6 @@ __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t sh
     }
 }
 
-// Grid barrier on a monotonic counter: arrive, then wait until `target` arrivals are in (wrap-safe).  One lane polls
-// with sc1 loads; bounded: a workgroup that was never dispatched (foreign load on the device) must not hang the rest.
-__device__ __forceinline__ bool mid_barrier(uint32_t* arrive, uint32_t target, uint32_t* status, uint32_t tid) {
-    __shared__ uint32_t s_ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are out before anyone is told
-    __syncthreads();
-    if (tid == 0) {
-        atomicAdd(arrive, 1u);
-        uint32_t spins = 0;
-        bool ok = true;
-        while ((int32_t)(ld_agent(arrive) - target) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { ok = false; break; }
-        }
-        if (!ok) st_agent(status, STATUS_TIMEOUT);
-        s_ok = ok ? 1u : 0u;
-    }
-    __syncthreads();
-    return s_ok != 0u;
-}
-
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
@@ -123,57 +130,138 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
                                                            uint32_t* status, uint32_t n, uint32_t descending) {
     using V = typename ValT<VB>::type;
     using VA = typename SC1T<VB>::type;
+    const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)scratch[MID_CTR]) + 1u;  // constant while K1 runs
     constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
     constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];
     __shared__ uint32_t s_dpre[RADIX], s_gbase[RADIX], s_wtot[4], s_max;
+    __shared__ uint32_t s_owned[MID_MAX_TILES];  // tiles this workgroup has claimed: its own first, then the adopted ones
+    __shared__ uint32_t s_ctl[4];                // [0] claim result / adopt result, [1] first tile whose flag is missing, [2] failed
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x, tiles = gridDim.x;
-    const uint32_t tile_base = tile * TILE;
-    const uint32_t count = n - tile_base < TILE ? n - tile_base : TILE;  // valid slots [0, count)
+    const uint32_t tiles = gridDim.x;
     const uint32_t my_base = wave * (64u * KPT) + lane;
     uint32_t* whist = s_whist + wave * RADIX;
-    uint32_t* arrive = scratch + MID_ARRIVE;
-    uint32_t barrier_no = 0;
+    uint32_t* claim = scratch + MID_CLAIM;
+    uint32_t* aflag = scratch + MID_AFLAG;
+    uint32_t* bflag = scratch + MID_BFLAG;
+    if (GS_FAULT_MID_ABSENT(blockIdx.x)) return;
 
     uint32_t key[KPT];
     V val[VB != 0 ? KPT : 1];
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t slot = my_base + i * 64u;
-        const uint32_t ci = tile_base + (slot < count ? slot : count - 1u);
-        key[i] = keys[ci];
-        if constexpr (VB != 0) val[i] = reinterpret_cast<const V*>(vals_)[ci];
-    }
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
-
-    // One partition step of the tile on the digit at `shift`: rank, tile counts -> table row, grid barrier, bases from
-    // the table (digit starts + the tiles in front), stage.  Leaves s_gbase[d] = global position of stage slot 0 of
-    // digit d's run minus its stage offset, and G (all tiles' count of this thread's digit) in the return value.
     uint32_t off[KPT / 2];
-    auto partition_step = [&](uint32_t shift, uint32_t* table, bool& alive) -> uint32_t {
+    uint32_t cur_tile = blockIdx.x, cur_base = 0, cur_count = 0;  // the tile in the registers
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // workgroup-uniform values stay scalar
+    auto load_tile = [&](uint32_t t, const uint32_t* kin, const void* vin, bool sc1) {
+        cur_tile = uni(t);
+        cur_base = t * TILE;
+        cur_count = n - cur_base < TILE ? n - cur_base : TILE;  // valid slots [0, count)
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t slot = my_base + i * 64u;
+            const uint32_t ci = cur_base + (slot < cur_count ? slot : cur_count - 1u);
+            if (sc1) {
+                key[i] = ld_sc1(&kin[ci]);
+                if constexpr (VB != 0) val[i] = (V)ld_sc1(&reinterpret_cast<const VA*>(vin)[ci]);
+            } else {
+                key[i] = kin[ci];
+                if constexpr (VB != 0) val[i] = reinterpret_cast<const V*>(vin)[ci];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < cur_count ? to_bits<KT>(key[i]) : 0xffffffffu;
+    };
+
+    // ---- claim this workgroup's own tile; its keys are requested meanwhile ----
+    if (tid == 0) {
+        s_ctl[0] = atomicMax(&claim[blockIdx.x], epoch) < epoch ? 1u : 0u;
+        s_ctl[2] = 0u;
+        s_owned[0] = blockIdx.x;
+    }
+    // a timeout of an earlier call is not this call's: the first workgroup of the call to get here clears the status word
+    // (long before any spin of this call can expire); another wave, so that the two atomics fly together
+    if (tid == 64 && atomicMax(&scratch[MID_RESET], epoch) < epoch) st_agent(status, STATUS_OK);
+    load_tile(blockIdx.x, keys, vals_, false);
+    __syncthreads();
+    if (uni(s_ctl[0]) == 0u) return;  // somebody adopted the tile while this workgroup was waiting to be dispatched
+    uint32_t n_owned = 1;        // uniform
+    bool own_in_regs = true;     // uniform: the registers still hold the own tile as loaded above
+
+    // rank the tile in the registers on the digit at `shift`, publish its counts as row cur_tile of `table` (flag = tag)
+    uint32_t run = 0, scan_incl = 0;  // of this thread's digit: the tile's count (dummies included), its inclusive scan
+    auto rank_and_publish = [&](uint32_t shift, uint32_t* table, uint32_t tag, bool publish) {
         for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
         if (tid == 0) s_max = 0;
         __syncthreads();
-        mid_rank<RANK, KPT>(key, shift, my_base, count, whist, off);
+        mid_rank<RANK, KPT>(key, shift, my_base, cur_count, whist, off);
         __syncthreads();
-        uint32_t run = 0, scan_incl = 0, mine = 0;
         if (tid < RADIX) {
+            run = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
                 const uint32_t c = s_whist[w * RADIX + tid];
                 s_whist[w * RADIX + tid] = run;
                 run += c;
             }
-            mine = run - ((RANK == 0 && tid == RADIX - 1) ? TILE - count : 0u);  // real keys only
-            st_sc1(&table[tile * RADIX + tid], mine);
+            const uint32_t mine = run - ((RANK == 0 && tid == RADIX - 1) ? TILE - cur_count : 0u);  // real keys only
+            if (publish) st_sc1(&table[cur_tile * RADIX + tid], mine);
             scan_incl = wave_inclusive_scan_dpp(run);
             if (lane == 63) s_wtot[wave] = scan_incl;
         }
-        alive = mid_barrier(arrive, (++barrier_no) * tiles, status, tid);
+        if (publish) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are out before anyone is told
+            __syncthreads();
+            if (tid == 0) st_sc1(&aflag[cur_tile], tag);
+        } else {
+            __syncthreads();
+        }
+    };
+    // wait until every tile's flag word has reached `tag`.  adopt: a tile nobody has claimed is taken over (its counts are
+    // published by this workgroup at once, its scatter follows this workgroup's own).  false = gave up (status word set).
+    auto wait_flags = [&](const uint32_t* flags, uint32_t tag, bool adopt, uint32_t shift, uint32_t* table) -> bool {
+        uint32_t spins = 0;  // uniform
+        if (tid == 0) s_ctl[1] = 0xffffffffu;
+        __syncthreads();
+        for (;;) {
+            // lane t watches tile t's flag: a few polls on its own (the common case ends here: one barrier), then the
+            // workgroup looks at who is still missing
+            if (tid < tiles) {
+                bool ready = false;
+                for (uint32_t i = 0; i < 8u && !ready; ++i) {
+                    ready = (int32_t)(ld_sc1(&flags[tid]) - tag) >= 0;
+                    if (!ready) __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ready) atomicMin(&s_ctl[1], tid);
+            }
+            __syncthreads();
+            const uint32_t missing = uni(s_ctl[1]);
+            if (missing == 0xffffffffu) return true;
+            __syncthreads();  // everybody has read the verdict
+            if (tid == 0) s_ctl[1] = 0xffffffffu;
+            __syncthreads();
+            spins += 8u;
+            if (adopt && spins >= GS_MID_ADOPT_SPINS) {
+                spins = 0;
+                if (tid == 0) s_ctl[0] = atomicMax(&claim[missing], epoch) < epoch ? 1u : 0u;
+                __syncthreads();
+                if (uni(s_ctl[0]) != 0u) {  // nobody had it: ours now
+                    if (tid == 0) s_owned[n_owned] = missing;
+                    ++n_owned;
+                    own_in_regs = false;
+                    load_tile(missing, keys, vals_, false);
+                    rank_and_publish(shift, table, tag, true);
+                }
+            } else if (spins > SPIN_LIMIT) {
+                if (tid == 0) { st_agent(status, STATUS_TIMEOUT); s_ctl[2] = 1u; }
+                __syncthreads();
+                return false;
+            }
+        }
+    };
+    // global bases of the tile in the registers from the complete table: leaves s_gbase[d] = global position of stage slot 0
+    // of digit d's run minus its stage offset, s_whist[w][d] += run offset, and returns G (all tiles' count of the digit)
+    auto bases = [&](uint32_t* table) -> uint32_t {
         uint32_t G = 0;
         if (tid < RADIX) {
             uint32_t wbase = 0;
@@ -195,7 +283,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
                 for (uint32_t j = 0; j < 8; ++j)
                     if (t0 + j < tiles) {
                         G += c[j];
-                        if (t0 + j < tile) front += c[j];
+                        if (t0 + j < cur_tile) front += c[j];
                     }
             }
             atomicMax(&s_max, G);
@@ -217,80 +305,107 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
-            if (RANK == 0 || my_base + i * 64u < count) {
+            if (RANK == 0 || my_base + i * 64u < cur_count) {
                 s_stage[lpos] = key[i];
                 if constexpr (VB != 0) s_vstage[lpos] = val[i];
             }
         }
         __syncthreads();
     };
-
-    // ---- MSD step on the top byte ----
-    bool alive = true;
-    uint32_t* table0 = scratch + MID_TABLE;
-    uint32_t* table1 = table0 + MID_MAX_TILES * RADIX;
-    const uint32_t G = partition_step(24, table0, alive);
-    if (!alive) return;
-    const bool lsd_route = s_max > TILE;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
-    __syncthreads();  // everybody has read s_max before the next partition step resets it
-    if (tile == 0 && tid < RADIX) {
-        scratch[MID_BSTART + tid] = s_gbase[tid] + s_dpre[tid];  // tile 0 has no tile in front: its base IS the digit start
-        scratch[MID_BCOUNT + tid] = G;
-        if (tid == 0) scratch[MID_ROUTE] = lsd_route ? 1u : 0u;
-    }
-    if (!lsd_route) {
-        stage(24);
-        // stable scatter into the alt buffer: stage slot j of digit d's run -> s_gbase[d] + j
+    auto scatter = [&](uint32_t shift, uint32_t* kout, void* vout, bool sc1, bool reverse) {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t i = tid + j * THREADS;
-            if (i < count) {
+            if (i < cur_count) {
                 const uint32_t kb = s_stage[i];
-                const uint32_t o = s_gbase[kb >> 24] + i;
-                alt[o] = from_bits<KT>(kb);
-                if constexpr (VB != 0) reinterpret_cast<V*>(valt_)[o] = s_vstage[i];
+                uint32_t o = s_gbase[(kb >> shift) & 255u] + i;
+                if (reverse) o = n - 1u - o;
+                if (sc1) {
+                    st_sc1(&kout[o], from_bits<KT>(kb));
+                    if constexpr (VB != 0) st_sc1(&reinterpret_cast<VA*>(vout)[o], (VA)s_vstage[i]);
+                } else {
+                    kout[o] = from_bits<KT>(kb);
+                    if constexpr (VB != 0) reinterpret_cast<V*>(vout)[o] = s_vstage[i];
+                }
             }
+        }
+    };
+
+    // ---- MSD step on the top byte ----
+    uint32_t* table0 = scratch + MID_TABLE;
+    uint32_t* table1 = table0 + MID_MAX_TILES * RADIX;
+    rank_and_publish(24, table0, mid_tag(epoch, 0), true);
+    if (!wait_flags(aflag, mid_tag(epoch, 0), true, 24, table0)) return;
+    if (!own_in_regs) {  // an adoption used the registers: back to the own tile
+        load_tile(blockIdx.x, keys, vals_, false);
+        rank_and_publish(24, table0, 0u, false);
+    }
+    const uint32_t G = bases(table0);
+    const bool lsd_route = uni(s_max) > TILE;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
+    __syncthreads();                      // everybody has read s_max before the next ranking resets it
+    // K2's plan, written by whoever owns tile 0 (its own workgroup, or the one that adopted it) while that tile is at hand
+    auto write_plan = [&]() {  // the registers / LDS hold tile 0
+        if (tid < RADIX) {
+            scratch[MID_BSTART + tid] = s_gbase[tid] + s_dpre[tid];  // tile 0 has no tile in front: its base IS the digit start
+            scratch[MID_BCOUNT + tid] = G;
+            if (tid == 0) {
+                scratch[MID_ROUTE] = lsd_route ? 1u : 0u;
+                scratch[MID_EPOCH] = epoch;
+            }
+        }
+    };
+    if (!lsd_route) {
+        for (uint32_t e = 0; e < n_owned; ++e) {  // uniform
+            if (e != 0) {
+                __syncthreads();
+                load_tile(s_owned[e], keys, vals_, false);
+                rank_and_publish(24, table0, 0u, false);
+                bases(table0);
+            }
+            if (cur_tile == 0u) write_plan();
+            stage(24);
+            scatter(24, alt, valt_, false, false);
         }
         return;
     }
+    for (uint32_t e = 0; e < n_owned; ++e)  // K2 only has to learn that there is nothing for it to do
+        if (s_owned[e] == 0u && tid == 0) {
+            scratch[MID_ROUTE] = 1u;
+            scratch[MID_EPOCH] = epoch;
+        }
 
-    // ---- LSD route: the four passes here, grid barriers between them; keys cross workgroups through sc1 accesses ----
+    // ---- LSD route: the four passes here, phase by phase; keys cross workgroups through sc1 accesses ----
     uint32_t* kbuf[2] = {keys, alt};
     void* vbuf[2] = {vals_, valt_};
 #pragma unroll 1
     for (uint32_t p = 0; p < 4; ++p) {
         const uint32_t shift = p * 8u;
-        if (p != 0) {  // reload this tile from where the previous pass wrote it
-            const uint32_t* kin = kbuf[p & 1u];
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t slot = my_base + i * 64u;
-                const uint32_t ci = tile_base + (slot < count ? slot : count - 1u);
-                key[i] = ld_sc1(&kin[ci]);
-                if constexpr (VB != 0) val[i] = (V)ld_sc1(&reinterpret_cast<const VA*>(vbuf[p & 1u])[ci]);
-            }
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
+        uint32_t* table = (p & 1u) ? table0 : table1;
+        const uint32_t tag_a = mid_tag(epoch, 1u + 2u * p), tag_b = mid_tag(epoch, 2u + 2u * p);
+        // counts of every owned tile (its input: what pass p-1 wrote)
+        for (uint32_t e = 0; e < n_owned; ++e) {
+            __syncthreads();
+            load_tile(s_owned[e], kbuf[p & 1u], vbuf[p & 1u], p != 0);
+            rank_and_publish(shift, table, tag_a, true);
         }
-        partition_step(shift, (p & 1u) ? table0 : table1, alive);
-        if (!alive) return;
-        stage(shift);
-        uint32_t* kout = kbuf[(p + 1u) & 1u];
-        const bool reverse = descending && p == 3;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t i = tid + j * THREADS;
-            if (i < count) {
-                const uint32_t kb = s_stage[i];
-                uint32_t o = s_gbase[(kb >> shift) & 255u] + i;
-                if (reverse) o = n - 1u - o;
-                st_sc1(&kout[o], from_bits<KT>(kb));
-                if constexpr (VB != 0) st_sc1(&reinterpret_cast<VA*>(vbuf[(p + 1u) & 1u])[o], (VA)s_vstage[i]);
+        if (!wait_flags(aflag, tag_a, false, shift, table)) return;
+        // scatter of every owned tile (the last one counted is still in the registers)
+        for (uint32_t e = n_owned; e-- > 0;) {
+            if (e + 1 != n_owned) {
+                __syncthreads();
+                load_tile(s_owned[e], kbuf[p & 1u], vbuf[p & 1u], p != 0);
+                rank_and_publish(shift, table, 0u, false);
+            }
+            bases(table);
+            stage(shift);
+            scatter(shift, kbuf[(p + 1u) & 1u], vbuf[(p + 1u) & 1u], true, descending && p == 3);
+            if (p != 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) st_sc1(&bflag[cur_tile], tag_b);
             }
         }
-        if (p != 3) {  // everybody has written pass p's output before anybody reads it
-            if (!mid_barrier(arrive, (++barrier_no) * tiles, status, tid)) return;
-        }
+        if (p != 3 && !wait_flags(bflag, tag_b, false, shift, table)) return;  // everybody has written pass p's output before anybody reads it
     }
 }
 
@@ -299,7 +414,8 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
 // ---------------------------------------------------------------------------
 template <int VB, int KT, int RANK, int THREADS_ = (int)MID_THREADS, int KPT_ = (int)MID_KPT>
 __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, const uint32_t* alt, void* vals_, const void* valt_,
-                                                               uint32_t* scratch, uint32_t n, uint32_t descending) {
+                                                               uint32_t* scratch, const uint32_t* status, uint32_t n,
+                                                               uint32_t descending) {
     using V = typename ValT<VB>::type;
     constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
     constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
@@ -308,10 +424,13 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
     __shared__ uint32_t s_whist[WAVES * RADIX];
     __shared__ uint32_t s_wtot[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) scratch[MID_ARRIVE] = 0u;  // K1 is over: the barrier counter is idle again
-    if (scratch[MID_ROUTE] != 0u) return;  // K1 ran the LSD passes itself
+    const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)scratch[MID_CTR]) + 1u;  // (advanced when ALL of K2 is through)
+    // K2's licence: the plan below is THIS call's (epoch) and no workgroup of K1 gave up (status).  Otherwise the bucket
+    // table may be an earlier call's — of another n — and nothing may be written.
+    bool work = scratch[MID_EPOCH] == epoch && *status == STATUS_OK && scratch[MID_ROUTE] == 0u;  // (route 1: K1 ran the LSD passes itself)
     const uint32_t start = scratch[MID_BSTART + blockIdx.x], count = scratch[MID_BCOUNT + blockIdx.x];
-    if (count == 0u) return;
+    if (count == 0u || count > TILE || start > n || count > n - start) work = false;  // (the last three cannot happen with a valid plan)
+    if (work) {
     const uint32_t my_base = wave * (64u * KPT) + lane;
     uint32_t* whist = s_whist + wave * RADIX;
     uint32_t key[KPT];
@@ -376,6 +495,21 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
             const uint32_t o = descending ? n - 1u - idx : idx;
             keys[o] = from_bits<KT>(key[i]);
             if constexpr (VB != 0) reinterpret_cast<V*>(vals_)[o] = val[i];
+        }
+    }
+    }  // work
+    // the call is over when every workgroup of K2 has read the epoch: the last one to finish advances it
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&scratch[MID_DONE], 1u) == gridDim.x - 1u) {
+        scratch[MID_DONE] = 0u;
+        if (epoch >= (1u << 26)) {  // long before tags could wrap: back to the state of a fresh handle
+            for (uint32_t i = 0; i < 3u * MID_MAX_TILES; ++i) scratch[MID_CLAIM + i] = 0u;
+            scratch[MID_RESET] = 0u;
+            scratch[MID_EPOCH] = 0u;
+            __threadfence();
+            scratch[MID_CTR] = 0u;
+        } else {
+            scratch[MID_CTR] = epoch;
         }
     }
 }

@@ -14,6 +14,9 @@
 #pragma once
 
 #define GS_FAULT_TILE(chain, tile) (((GS_EXP)&8) && (chain) == 3u && (tile) == 5u)
+// ... and in the two-launch mid-size sort every fourth workgroup of K1 behaves as if it had never been dispatched (the
+// others adopt its tile)
+#define GS_FAULT_MID_ABSENT(block) (((GS_EXP)&8) && ((block)&3u) == 1u)
 
 #if (GS_EXP & 2)
 #define GS_TRACE_SETUP()                                                                                                  \

@@ -155,10 +155,10 @@ constexpr uint32_t HX_SKEW = 0;  // a workgroup found the digit groups of its ke
 constexpr uint32_t HIST_WORDS = HIST_TABLE_WORDS + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
-// MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): barrier counter, route flag, bucket table,
-// two count tables of MID_MAX_TILES rows
+// MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): plan epoch, route flag, bucket table, per-tile
+// claim / flag words, two count tables of MID_MAX_TILES rows
 constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
-constexpr uint32_t SLAB_MID_WORDS = 64 + 2 * RADIX + 2 * 128 * RADIX;
+constexpr uint32_t SLAB_MID_WORDS = 1024 + 2 * 128 * RADIX;
 constexpr uint32_t SLAB_DESC = SLAB_MID + SLAB_MID_WORDS;
 static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
@@ -1625,7 +1625,7 @@ constexpr uint32_t SMALL_TILE_MAX = 1024 * 32;    // largest single-tile sort (k
 
 template <int SMALL_THREADS, int SMALL_KPT, int VB, int KT, int RANK>
 __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* keys, void* vals_, uint32_t n,
-                                                                   uint32_t descending) {
+                                                                   uint32_t descending, uint32_t* status) {
     using V = typename ValT<VB>::type;
     constexpr int KW = KeyWords<KT>::value;  // 64-bit keys: eight passes, both words staged
     constexpr int KPT = SMALL_KPT, WAVES = SMALL_THREADS / 64;
@@ -1639,6 +1639,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t my_base = wave * (64u * KPT) + lane;
     uint32_t* whist = s_whist + wave * RADIX;
+    if (tid == 0) st_agent(status, STATUS_OK);  // this sort cannot time out; an earlier call's verdict is not this call's
 
     uint32_t key[KPT];                      // low word (the only one for 32-bit keys)
     uint32_t keyh[KW == 2 ? KPT : 1];       // high word
@@ -1808,6 +1809,7 @@ __global__ __launch_bounds__(512) void lds_atomic_order_probe(uint32_t seed, uin
     if (lane == 0 && bad) atomicAdd(failures, bad);
 }
 
+#ifdef GS_TUNING  // calibration kernels: in the tuning build (libgpusort_tuning.so: tools/, bench.py's box_floor) only
 // Memory-floor kernel for tuning: the binning pass's exact global access shape
 // (wave-striped dword loads of a tile, coalesced dword stores) and one LDS
 // round trip, with no ranking and no look-back.
@@ -1849,6 +1851,7 @@ __global__ __launch_bounds__(256) void read_x4_kernel(const u32x4* in, uint32_t*
     }
     if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive
 }
+#endif  // GS_TUNING
 
 // ---------------------------------------------------------------------------
 // Fixtures: InitRandom and Validate.

@@ -275,7 +275,7 @@ class ShardedOneSweep:
             _lib.check(lib.gs_mgpu_last_plan(self._ctx, plan.ctypes.data_as(C.POINTER(C.c_uint32)), plan.size), "gs_mgpu_last_plan")
             d = _plan_dict(plan, self.world)
             self.last_counts = (d["send"], d["recv"])
-            self.last_split = "12-bit prefix" if self.profile()["fine_split"] else "top byte"
+            self.last_split = "12-bit prefix" if int(plan[3]) else "top byte"  # (profile() would wait for the local sort)
         return self._recv[:nr], (self._recv_v[:nr] if values is not None else None), nr
 
     # ---- the same steps driven from Python over an injected engine (CPU tests) ------------------------------------

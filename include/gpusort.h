@@ -115,8 +115,8 @@ gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
  * choice the library picks: the shape gs_onesweep_partition_size() reports for large
  * sorts (512x32 keys-only and 8-byte values, 1024x16 4-byte values) and 512x16
  * (8192-key tiles) up to 2^23 / 2^24 / 2^25 keys (keys-only / 4-byte / 8-byte values),
- * where it is faster.  512x32, 1024x16 and 512x16 exist for every key and value type;
- * 256x32 and 256x16 (tuning) for uint32 keys only.  Env GPUSORT_SHAPE="TxK" sets it at create. */
+ * where it is faster.  512x32, 1024x16 and 512x16 exist for every key and value type
+ * (the tuning build libgpusort_tuning.so adds 256x32, 256x16 and 512x20 for uint32 keys).  Env GPUSORT_SHAPE="TxK" sets it at create. */
 gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread);
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
 /* Ranking algorithm inside a tile: 0 = 64-lane ballot multi-split (the
@@ -145,10 +145,6 @@ gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
-/* Tuning aid: global access pattern of a DigitBinningPass without ranking or
- * look-back (memory floor of the tile shape). */
-gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_t threads,
-                              uint32_t keys_per_thread, void* stream);
 /* Instrumented builds only (-DGS_EXP=2, tools/trace_tiles.py): device buffer of 4 passes x grid x 8 words that
  * receives per-tile phase timestamps.  A no-op in the product build. */
 gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf);
@@ -161,6 +157,9 @@ gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf);
  * flight) — all four must be 0 — and [4 + q] the keys the descriptors of the call's q-th pass account for (== n
  * for every pass that ran, 0 for a dropped identity pass).  All zero after a single-tile sort (no scan state). */
 gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream);
+/* Test hook: overwrite the device status word gs_onesweep_check() reads (e.g. GS_ERR_TIMEOUT) — every sort must reset it
+ * itself, whatever route it takes.  Synchronous. */
+gs_status gs_debug_poke_status(gs_onesweep* h, uint32_t word, void* stream);
 
 /* ---- structural entry points (parity tests, MSD split) --------------------
  * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
@@ -250,7 +249,8 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* ctx, const void* d_keys, const void*
  * ms[0] split (histogram + all-gather + plan + the host wait + partition pass), ms[1] bucket exchange,
  * ms[2] local sort, ms[3] total; bytes this rank sent to / received from OTHER ranks; whether the 12-bit split ran. */
 gs_status gs_mgpu_get_profile(gs_mgpu* ctx, float ms[4], uint64_t* bytes_sent, uint64_t* bytes_received, uint32_t* fine_split);
-/* The exchange plan of the last call: [0] keys received, [1] overflow, [2] largest bucket, [3] 0, then
+/* The exchange plan of the last call (host memory, no synchronisation): [0] keys received, [1] overflow, [2] largest bucket,
+ * [3] 1 if the split ran at the 12-bit prefix, then
  * send_counts[world], recv_counts[world], first_bin[world + 1]; `words` >= 4 + 3 * world + 1. */
 gs_status gs_mgpu_last_plan(gs_mgpu* ctx, uint32_t* plan, uint32_t words);
 gs_onesweep* gs_mgpu_sorter(gs_mgpu* ctx);               /* the local engine (tuning switches, gs_onesweep_check) */

@@ -55,6 +55,39 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
     assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
 
 
+def test_mid_route_adopts_the_tiles_of_absent_workgroups(gpu):
+    """Round-2 review, item 2 (reference: EmulatedDeadlocking.cu:36-37,339-345): in the fault build every fourth workgroup of the
+    mid-size route's first kernel behaves as if it had never been dispatched.  The others adopt its tile — counts and
+    scatter — so every size class of the route, both routes inside it (MSD + bucket sorts; the LSD passes for a skewed top
+    byte), keys and pairs come out exact, with GS_OK."""
+    out = _run("libgpusort_fault.so", """
+        import sys, time, torch
+        sys.path.insert(0, %r)
+        import gpusorting_amd as g
+        cases = [(20000, 0, False), (100003, 0, True), ((1 << 20) - 5, 0, False), ((1 << 21) + 5, 0, True), (1 << 22, 0, False),
+                 (300000, 3, False), ((1 << 20) + 77, 3, True)]          # preset 4: the top byte is 0 for most keys -> LSD route
+        for n, preset, pairs in cases:
+            k = torch.empty(n, dtype=torch.int32, device="cuda")
+            g.init_random(k, 21, preset)
+            if preset:
+                k &= 0x00FFFFFF                                          # one top-byte bucket holds everything
+            v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+            ref = torch.sort(k.to(torch.int64) & 0xffffffff, stable=True)
+            s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+            t0 = time.time()
+            for rep in range(2):                                         # the handle's next epoch must work as well
+                if rep: g.init_random(k, 21, preset); k &= (0x00FFFFFF if preset else -1)
+                if rep and pairs: v.copy_(torch.arange(n, dtype=torch.int32, device="cuda"))
+                s.sort(k, v)
+                s.check()                                                # raises on GS_ERR_TIMEOUT
+            ok = bool(((k.to(torch.int64) & 0xffffffff) == ref.values).all().item())
+            if pairs:
+                ok = ok and bool((v.to(torch.int64) == ref.indices).all().item())
+            print("RESULT", "exact" if ok else "WRONG", n, "seconds", round(time.time() - t0, 3))
+    """)
+    assert out.count("RESULT exact") == 7, out
+
+
 def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
     out = _run("libgpusort_fault_nofallback.so", """
         import sys, time, torch

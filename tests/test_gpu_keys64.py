@@ -136,3 +136,24 @@ def test_keys64_validate_counts_inversions(gpu, oracle):
         part = _dev(np.ascontiguousarray(keys[:2000]))
         assert gpu.validate(part, key_type=gpu.KEY_UINT64 + kt, order=0) == int(np.count_nonzero(bits[:-1] > bits[1:]))
         assert gpu.validate(part, key_type=gpu.KEY_UINT64 + kt, order=1) == int(np.count_nonzero(bits[:-1] < bits[1:]))
+
+
+def test_keys64_profile_slots_are_consistent(gpu, oracle):
+    """ADVICE (round 2): the second round of a 64-bit sort re-recorded the events of the first, so slots went negative and the
+    total covered half the sort.  Now round 1 is charged to slot 6 (pass 3): every slot >= 0, their sum == the total (the
+    slots are consecutive event pairs), and the total is about twice a 32-bit sort's."""
+    import torch
+    n = 1 << 22
+    rng = np.random.default_rng(5)
+    dk = _dev(rng.integers(0, 2**64, size=n, dtype=np.uint64))
+    s = gpu.OneSweep(n, gpu.ORDER_ASCENDING, gpu.KEY_UINT64)
+    s.set_profiling(True)
+    for _ in range(2):
+        s.sort(dk)
+        torch.cuda.synchronize()
+    p = s.get_profile()
+    parts = [p[k] for k in ("clear", "global_histogram", "scan", "pass0", "pass1", "pass2", "pass3")]
+    assert all(x >= 0.0 for x in parts), p
+    assert abs(sum(parts) - p["total"]) < 0.02 * p["total"] + 0.005, p
+    assert p["pass3"] > 2.0 * p["pass0"], p   # pass 3 of round 0 + the whole second round
+    s.close()

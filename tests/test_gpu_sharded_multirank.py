@@ -38,7 +38,7 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
     k0 = keys.cpu().numpy().view(np.uint32).copy()
     v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
-    s = ShardedOneSweep(shard, slack=slack, pairs=pairs, value_bytes=4)   # HipLocalEngine
+    s = ShardedOneSweep(shard, slack=slack, pairs=pairs, value_bytes=4)   # the C++ pipeline (gs_onesweep_sort_sharded) over a host-staged transport
     bk, bv, nb = s.sort(keys, values=vals)
     torch.cuda.synchronize()
     s.engine.sorter.check()

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpusorting_amd import _lib  # noqa: E402
 
 n = 1 << 28
-lib = _lib.load()
+lib = _lib.load_tuning()  # calibration kernels live in the tuning build
 a = torch.empty(n, dtype=torch.int32, device="cuda"); a.random_()
 b = torch.empty_like(a)
 sp = int(torch.cuda.current_stream().cuda_stream)

@@ -46,7 +46,7 @@ def main():
     print(f"torch copy: {ms:.3f} ms = {8.0*n/ms/1e6:.0f} GB/s (read+write)", flush=True)
     sp = int(torch.cuda.current_stream().cuda_stream)
     for (t, k) in ((512, 16), (1024, 16), (256, 32)):
-        ms = timed(lambda: lib.gs_debug_copy_floor(keys.data_ptr(), alt.data_ptr(), n, t, k, sp))
+        ms = timed(lambda: _lib.load_tuning().gs_debug_copy_floor(keys.data_ptr(), alt.data_ptr(), n, t, k, sp))
         print(f"copy_floor {t}x{k}: {ms:.3f} ms = {8.0*n/ms/1e6:.0f} GB/s", flush=True)
     fails = C.c_uint64(1)
     st = lib.gs_selftest_lds_atomic_order(2000, 1, C.byref(fails), sp)
