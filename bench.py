@@ -89,9 +89,10 @@ def cpu_baseline(log2n: int):
 
 def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys):
     """HBM bytes per DigitBinningPass launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
-    separate rocprofv3 --pmc passes of this same command and committed under profiles/); None if the committed
+    separate rocprofv3 --pmc passes of this same command and committed under profiles/) — a BORROWED number: it was
+    measured by the builder's rocprofv3 runs, not by this run, and the block says so.  None if the committed
     measurement is for another workload/tile shape."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -100,16 +101,61 @@ def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys):
     if log2_keys != 28 or entropy or shape:
         return None
     d = json.load(open(path))
+    src = f"profiles/{name} (builder-run rocprofv3 --pmc passes of the same command; NOT measured by this run)"
     if vb:
         d = d.get(f"pairs{vb}")
-        return d["traffic_bytes_per_launch"] if d else None
+        return {"bytes": d["traffic_bytes_per_launch"], "source": src} if d else None
     m = d.get("tile_keys")
     if m is not None:
-        return d["traffic_bytes_per_launch"] if m == tile_keys else None
-    return d["traffic_bytes_per_launch"] if f"<{tile_keys // 32},32,0,0," in d["kernel"] else None
+        return {"bytes": d["traffic_bytes_per_launch"], "source": src} if m == tile_keys else None
+    return {"bytes": d["traffic_bytes_per_launch"], "source": src} if f"<{tile_keys // 32},32,0,0," in d["kernel"] else None
 
 
-def roofline_block(n, vb, prof, traffic):
+def box_floor(n):
+    """What THIS box streams, measured in this process with the tuning build's calibration kernels (libgpusort_tuning.so; never
+    part of the product path): a read-only 16-byte sweep of n keys (the GlobalHistogram's floor) and the DigitBinningPass's own
+    access shape without ranking and look-back — wave-striped dword loads of a 16 384-key tile, one LDS round trip, coalesced
+    dword stores, SEQUENTIAL output (the pass's floor; steady state = a copy that follows a copy).  floor = read + 4 x copy."""
+    from gpusorting_amd import _lib
+    try:
+        lib = _lib.load_tuning()
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+    a = torch.empty(n, dtype=torch.int32, device="cuda")
+    b = torch.empty(n, dtype=torch.int32, device="cuda")
+    a.random_()
+    sp = int(torch.cuda.current_stream().cuda_stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+
+    def seq():
+        ev[0].record()
+        lib.gs_debug_copy_floor(a.data_ptr(), b.data_ptr(), n, 0, 3, sp)   # read-only sweep
+        ev[1].record()
+        src, dst = a, b
+        for i in range(5):
+            lib.gs_debug_copy_floor(src.data_ptr(), dst.data_ptr(), n, 512, 32, sp)  # tile-shaped copy
+            ev[2 + i].record()
+            src, dst = dst, src
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
+
+    seq()
+    runs = [seq() for _ in range(4)]
+    read_ms = min(r[0] for r in runs)
+    first_copy = min(r[1] for r in runs)
+    steady = sorted(sum(r[3:6]) / 3.0 for r in runs)[len(runs) // 2]
+    floor_ms = read_ms + first_copy + 3.0 * steady
+    return {
+        "read_only_sweep_ms": read_ms, "read_GBps": 4.0 * n / read_ms / 1e6,
+        "tile_copy_ms_first_after_read": first_copy, "tile_copy_ms_steady": steady, "tile_copy_GBps_steady": 8.0 * n / steady / 1e6,
+        "floor_ms": floor_ms, "floor_GKeys_per_s": n / floor_ms / 1e6,
+        "how": "libgpusort_tuning.so gs_debug_copy_floor: 16-byte grid-stride read sweep; 512x32 tile copy (wave-striped dword loads, LDS "
+               "round trip, coalesced dword stores, sequential output); floor = read + first copy + 3 x steady-state copy, HIP events, "
+               "best / median of 4 sequences, this process, this box",
+    }
+
+
+def roofline_block(n, vb, prof, traffic, tile_keys=None, rank_mode=None, floor=None):
     """The dominant kernel (one DigitBinningPass launch) against the HBM peak: algorithmic bytes per launch =
     (4 + 4 key bytes + 2 x value bytes) x n, divided by the launch's average duration from HIP
     events recorded on the sort's own stream."""
@@ -119,7 +165,9 @@ def roofline_block(n, vb, prof, traffic):
     achieved = bpk_pass * n / (pass_ms * 1e-3) / 1e9
     whole = bpk_sort * n / (prof["total"] * 1e-3) / 1e9
     return {
-        "bound": "hbm", "kernel": "digit_binning_kernel (one 8-bit DigitBinningPass)",
+        "bound": "hbm",
+        "kernel": ("digit_binning_dual_kernel (one 8-bit DigitBinningPass per launch; persistent workgroups; plain form for even keys, "
+                   "position-chain form when the device plans PF_POS)") if not vb else "digit_binning_kernel (one 8-bit DigitBinningPass)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
         "algorithmic_bytes_per_launch": bpk_pass * n, "avg_launch_ms": pass_ms,
@@ -131,6 +179,14 @@ def roofline_block(n, vb, prof, traffic):
             "read_only_frac_of_8000": (4 + 4 * (4 + vb)) * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
         "per_kernel_ms": prof,
+        "tile_keys": tile_keys, "rank_mode": rank_mode,
+        # the kernel furthest below its roofline (4 B/key read): the GlobalHistogram against the same peak
+        "global_histogram": {"algorithmic_bytes": 4 * n, "ms": prof["global_histogram"],
+                             "achieved_GBs": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9,
+                             "frac": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        **({"frac_of_box_floor": {"pass": floor["tile_copy_ms_steady"] / pass_ms, "whole_sort": floor["floor_ms"] / prof["total"],
+                                  "global_histogram": floor["read_only_sweep_ms"] / prof["global_histogram"]}}
+           if floor and "floor_ms" in floor and not vb else {}),
     }
 
 
@@ -174,8 +230,9 @@ def measure_single(g, n, vb, entropy, steps, warm=1, prof_reps=3):
             acc[k_] = acc.get(k_, 0.0) + v_ / prof_reps
     sorter.set_profiling(False)
     tile = sorter.partition_size
+    rank = sorter.rank_mode
     sorter.close()
-    return n * steps / dt / 1e9, dt / steps * 1e3, acc, ok, tile
+    return n * steps / dt / 1e9, dt / steps * 1e3, acc, ok, (tile, rank)
 
 
 def more_block(g, n, log2, steps):
@@ -186,25 +243,94 @@ def more_block(g, n, log2, steps):
     ent_bits = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201
     out = {"note": "measured after the headline region, same process; steps per entry = %d" % steps}
     for vb, name, cfg in ((4, "pairs_u32", 2), (8, "pairs_u64", 4)):
-        gk, ms, prof, ok, tile = measure_single(g, n, vb, 0, steps)
+        gk, ms, prof, ok, (tile, rk) = measure_single(g, n, vb, 0, steps)
         out[name] = {
             "workload": f"2^{log2} (uint32 key, uint{8 * vb} value) pairs OneSweep, 1 MI355X (BASELINE configs[{cfg}])",
             "value": gk, "unit": "GKeys/s", "ms_per_sort": ms, "steps": steps, "tile_keys": tile, "verified_sorted": bool(ok),
             "dtype": f"u32 keys + u{8 * vb} values",
-            "roofline": roofline_block(n, vb, prof, pmc_traffic(log2, vb, 0, "", tile)),
+            "roofline": roofline_block(n, vb, prof, pmc_traffic(log2, vb, 0, "", tile), tile, rk),
         }
     rows = {}
     for vb, name in ((0, "keys"), (8, "pairs_u64")):
         row = []
         for preset in range(5):
-            gk, ms, prof, ok, tile = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
+            gk, ms, prof, ok, (tile, rk) = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
             pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
             row.append({"preset": preset + 1, "entropy_bits": ent_bits[preset], "value": gk, "unit": "GKeys/s", "ms_per_sort": ms,
                         "verified_sorted": bool(ok), "global_histogram_ms": prof["global_histogram"], "avg_pass_ms": pass_ms,
+                        "tile_keys": tile, "rank_mode": rk,
+                        "global_histogram_frac_of_8000": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "pass_frac_of_8000": (8 + 2 * vb) * n / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         rows[name] = row
     out["entropy_sweep"] = rows
+    out["entropy_sweep_note"] = ("keys-only sorts of skewed keys (presets 2-5) run on position chains in every pass (decided on the "
+                                 "device: the histogram kernel finds the digit groups uneven); counting passes use 12 288-key tiles")
+    # ---- 64-bit keys: two stable 4-pass rounds over 8-byte elements ----
+    n64 = min(n, 1 << 27)
+    k64 = [torch.empty(n64, dtype=torch.int64, device="cuda") for _ in range(3)]
+    a64 = torch.empty(n64, dtype=torch.int64, device="cuda")
+    s64 = g.OneSweep(n64, key_type=g.KEY_UINT64)
+    for t in k64:
+        t.random_(-(1 << 62), 1 << 62)
+    s64.sort(k64[0], alt_keys=a64)
+    for t in k64:
+        t.random_(-(1 << 62), 1 << 62)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in k64:
+        s64.sort(t, alt_keys=a64)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / len(k64)
+    s64.check()
+    ok64 = g.validate(k64[-1], key_type=g.KEY_UINT64) == 0
+    s64.close()
+    out["keys64"] = {"workload": f"2^{n64.bit_length() - 1} uniform uint64 keys, keys-only", "value": n64 / dt / 1e9, "unit": "GKeys/s",
+                     "ms_per_sort": dt * 1e3, "steps": len(k64), "verified_sorted": bool(ok64),
+                     "bytes_per_key": 2 * 8 + 8 * 16, "achieved_GBs": (2 * 8 + 8 * 16) * n64 / dt / 1e9,
+                     "frac_of_8000": (2 * 8 + 8 * 16) * n64 / dt / 1e9 / HBM_PEAK_GBS,
+                     "structure": "two rounds (low word, high word) of histogram + scan + 4 passes on 8192-element tiles"}
+    del k64, a64
+    torch.cuda.empty_cache()
+    # ---- size sweep (reference: GPUSortingD3D12/Tests.h:392-393,415-416: 2^10 .. 2^27) ----
+    out["size_sweep"] = size_sweep(g)
     return out
+
+
+def size_sweep(g, sorts=10):
+    """2^10 .. 2^27 keys, keys-only and (u32, u32) pairs, `sorts` back-to-back sorts of distinct pre-generated inputs per point
+    (HIP events around the batch): microseconds per sort and GKeys/s."""
+    rows = {"keys": [], "pairs_u32": [], "sorts_per_point": sorts,
+            "routes": "n <= 8192: one workgroup, one launch; <= 2^20 (keys-only 2^22, u32 values 2^21): two launches (MSD pass + LDS "
+                      "bucket sorts); above: GlobalHistogram + Scan + 4 DigitBinningPass"}
+    for vb, name in ((0, "keys"), (4, "pairs_u32")):
+        for lg in range(10, 28):
+            n = 1 << lg
+            nb = max(1, min(sorts, (1 << 29) // (n * 4)))
+            ks = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(nb)]
+            vs = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(nb)] if vb else [None] * nb
+            alt = torch.empty(n, dtype=torch.int32, device="cuda")
+            valt = torch.empty(n, dtype=torch.int32, device="cuda") if vb else None
+            s = g.OneSweep(n, mode=g.MODE_PAIRS if vb else g.MODE_KEYS_ONLY, value_bytes=vb)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            total, done, ok = 0.0, 0, True
+            for rnd in range(-1, (sorts + nb - 1) // nb):   # round -1 = warm-up
+                for i in range(nb):
+                    g.init_random(ks[i], 10 + done + i, 0, vs[i])
+                torch.cuda.synchronize()
+                a.record()
+                for i in range(nb):
+                    s.sort(ks[i], vs[i], alt_keys=alt, alt_values=valt)
+                b.record()
+                b.synchronize()
+                if rnd >= 0:
+                    total += a.elapsed_time(b)
+                    done += nb
+            s.check()
+            ok = g.validate(ks[-1], vs[-1]) == 0
+            s.close()
+            us = total / done * 1e3
+            rows[name].append({"log2_keys": lg, "us_per_sort": round(us, 2), "GKeys_per_s": round(n / us / 1e3, 3), "sorted": bool(ok)})
+    return rows
 
 
 def main():
@@ -385,6 +511,13 @@ def main():
             dist.destroy_process_group()
         return
 
+    floor = None
+    if world == 1 and not args.no_more:
+        bufs.clear()      # (the calibration buffers need room)
+        vbufs.clear()
+        last = out_k = out_v = None
+        torch.cuda.empty_cache()
+        floor = box_floor(n)
     total_keys = n * world * K
     value = total_keys / elapsed / 1e9
     ms_per_step = elapsed / K * 1e3
@@ -402,8 +535,11 @@ def main():
             "keys_per_gpu": n, "entropy_preset": args.entropy + 1, "generator": "InitRandom seed 10+i (+1000*rank)",
             "tile_keys": sorter.partition_size, "verified_sorted": bool(sorted_ok and total_ok),
         },
-        "roofline": roofline_block(n, args.pairs, prof, pmc_traffic(args.log2_keys, args.pairs, args.entropy, args.shape, sorter.partition_size)),
+        "roofline": roofline_block(n, args.pairs, prof, pmc_traffic(args.log2_keys, args.pairs, args.entropy, args.shape, sorter.partition_size),
+                                   sorter.partition_size, sorter.rank_mode, floor),
     }
+    if floor is not None:
+        out["box_floor"] = floor
     if mgpu is not None:
         out["multi_gpu"] = mgpu
     if world == 1 and not args.pairs and not args.entropy and not args.shape and not args.no_more:

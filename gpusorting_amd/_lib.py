@@ -45,6 +45,7 @@ _PROTOS = [
     ("gs_onesweep_set_shape", _int, [_vp, _u32, _u32]),
     ("gs_onesweep_get_partition_size", _u32, [_vp]),
     ("gs_onesweep_set_rank_mode", _int, [_vp, _int]),
+    ("gs_onesweep_get_rank_mode", _int, [_vp]),
     ("gs_onesweep_set_small_path", _int, [_vp, _int]),
     ("gs_onesweep_set_skip_passes", _int, [_vp, _int]),
     ("gs_onesweep_set_mid_path", _int, [_vp, _int]),

@@ -614,6 +614,8 @@ gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode) {
     return GS_OK;
 }
 
+int gs_onesweep_get_rank_mode(gs_onesweep* h) { return h ? h->rank_mode : -1; }
+
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream) {
     if (!h_failures || iters == 0) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -145,6 +145,11 @@ class OneSweep:
     def set_shape(self, threads: int, keys_per_thread: int) -> None:
         check(self._lib.gs_onesweep_set_shape(self._h, threads, keys_per_thread), "gs_onesweep_set_shape")
 
+    @property
+    def rank_mode(self) -> int:
+        """0 = ballot multi-split, 1 = returning LDS atomic (the library's choice after its device probe, or the caller's)."""
+        return int(self._lib.gs_onesweep_get_rank_mode(self._h))
+
     def set_rank_mode(self, mode: int) -> None:
         check(self._lib.gs_onesweep_set_rank_mode(self._h, mode), "gs_onesweep_set_rank_mode")
 

@@ -124,6 +124,7 @@ uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
  * returning LDS atomic per key, valid only if gs_selftest_lds_atomic_order()
  * reports 0 failures on this device. */
 gs_status gs_onesweep_set_rank_mode(gs_onesweep* h, int mode);
+int gs_onesweep_get_rank_mode(gs_onesweep* h); /* the mode in use (after the create-time probe): 0 or 1; -1 for a null handle */
 /* Small inputs are sorted by ONE workgroup in one launch (all four passes in LDS): n <= 8192 in every
  * mode, n <= 16384 for keys-only and 4-byte values, n <= 32768 for keys-only — unless this is switched off
  * (tests use 0 to push small sizes through the tiled path as well). */
