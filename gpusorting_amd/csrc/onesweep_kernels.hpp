@@ -865,6 +865,9 @@ __device__ __forceinline__ void binning_body(
         }
     }
     GS_TRACE_SETUP();
+    // (measured and not kept, PERSIST: the next tile's ticket drawn while this tile is scattered — +0.5 .. 1 %: a tile claimed
+    //  4 us before its workgroup starts on it publishes its counts 4 us late for the tiles behind it,
+    //  profiles/r03_ab_ticket_ahead.txt)
 #pragma unroll 1
     for (;;) {  // PERSIST: one tile after the other until every chain is claimed; otherwise ONE tile per workgroup
     if constexpr (PERSIST) __syncthreads();  // the last tile's readers of the stage and of s_misc are through
