@@ -18,7 +18,10 @@ gpusorting_amd/lib/libgpusort_tuning.so: $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -DGS_MINIMAL -DGS_TUNING $(SRC) -o $@
 oracle:
 	$(MAKE) -C oracle
-tools: build/gpusorting_main build/gpusorting_d3d12_main build/rocprim_compare
+tools: build/gpusorting_main build/gpusorting_d3d12_main build/rocprim_compare build/mgpu_main
+build/mgpu_main: tools/mgpu_main.cpp include/gpusort.h $(LIB)
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Iinclude tools/mgpu_main.cpp -Lgpusorting_amd/lib -lgpusort -lpthread -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@
 build/gpusorting_d3d12_main: tools/gpusorting_d3d12_main.cpp include/gpusort/GPUSortBase.hpp $(LIB)
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Iinclude tools/gpusorting_d3d12_main.cpp -Lgpusorting_amd/lib -lgpusort -Wl,-rpath,'$$ORIGIN/../gpusorting_amd/lib' -o $@

@@ -70,6 +70,8 @@ _PROTOS = [
     ("gs_onesweep_sort_sharded", _int, [_vp, _vp, _vp, _u32, _int, _vp, _vp, _u32p, _vp]),
     ("gs_mgpu_get_profile", _int, [_vp, C.POINTER(C.c_float), _u64p, _u64p, _u32p]),
     ("gs_mgpu_last_plan", _int, [_vp, _u32p, _u32]),
+    ("gs_mgpu_check", _int, [_vp, _vp]),
+    ("gs_mgpu_debug_fail", _int, [_vp, _int]),
     ("gs_mgpu_sorter", _vp, [_vp]),
     ("gs_mgpu_set_force_exchange", _int, [_vp, _int]),
     ("gs_last_rccl_error", _int, []),

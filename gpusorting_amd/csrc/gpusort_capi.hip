@@ -340,8 +340,10 @@ inline int mid_class(uint32_t n, uint32_t vb) {
     return -1;
 }
 
+// values_ready (multi-GPU): an event behind which d_vals is complete — the keys already are, so GlobalHistogram + Scan (which read
+// keys only) run before the stream waits for it; the one- and two-launch routes wait first.
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
-                    gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb) {
+                    gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb, hipEvent_t values_ready = nullptr) {
     // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20 (2^21 for keys-only and
     // 4-byte values, 2^22 for keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
     // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
@@ -352,6 +354,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const bool use_mid = mid_cls >= 0;
 #endif
     if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
+        if (values_ready) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u, h->slab + SLAB_STATUS);
         h->last_tile = 0;
@@ -365,6 +368,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
 #ifndef GS_MINIMAL
     if (use_mid) {
         // one MSD pass + one LDS sort per top-byte bucket (a skewed top byte: the LSD passes inside the first kernel)
+        if (values_ready) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         g_mid[mid_cls][h->rank_mode][vb_index(vb)][kt](s, div_up(n, g_mid_tile[mid_cls]), static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys),
                                               d_vals, d_alt_vals, h->slab + gs::SLAB_MID, h->slab + SLAB_STATUS, n,
@@ -411,6 +415,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         PassPlan plan;
         gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word);
         if (st != GS_OK) return st;
+        if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
         for (uint32_t p = 0; p < 4; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
             const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);

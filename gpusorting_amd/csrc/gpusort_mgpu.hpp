@@ -11,9 +11,23 @@
 //   4. ONE small device-to-host copy (the plan: a few dozen words) and ONE event wait: RCCL's send/recv take their
 //      counts as host integers, so this wait is inherent in the exchange, and it is the only one
 //   5. the stable DigitBinningPass on the top byte groups the shard by destination (reusing the scan state of 1)
-//   6. bucket exchange: ONE ncclGroup of send/recv pairs for keys and values together — point-to-point on all
-//      xGMI links at once
-//   7. the local 4-pass OneSweep on the received bucket, in the caller's output buffers
+//   6. bucket exchange: grouped ncclSend / ncclRecv pairs — point-to-point on all xGMI links at once.  Pairs: the KEYS go
+//      first, on the caller's stream; the VALUES follow on a second communicator (ncclCommSplit) and a second stream, so
+//      that
+//   7. the local 4-pass OneSweep of the received bucket starts on the keys (GlobalHistogram + Scan read nothing else)
+//      while the values are still on the links; its first pass waits for them
+//   8. a one-word all-gather of every rank's status closes the call (see FAILURES)
+// Why grouped send/recv and not ncclAllToAllv (rccl.h:815, the call BASELINE.json names): RCCL implements AllToAllv as
+// exactly this group of sends and receives, but through one entry point that takes ONE buffer pair — keys and values
+// would be two calls on one communicator, serialised, and the call cannot skip empty peers or put a peer's two arrays
+// back to back.  GPUSORT_MGPU_ALLTOALLV=1 switches the exchange to ncclAllToAllv (one call per array) for comparison on
+// hardware; results are identical.
+// FAILURES.  A rank that fails alone must not leave its peers inside a collective.  Before the gather (histogram,
+// allocation, launch errors): the rank gathers a POISONED row (MSD_POISON in bin 0), the plan kernel of every rank sees
+// it, and all ranks return GS_ERR_COMM together right after the call's one host wait.  After the plan: the rank still
+// runs its exchange as planned (its peers' receives complete), reports its status in the closing all-gather, and
+// returns its own error; the peers learn it from gs_mgpu_check() — GS_ERR_COMM — at their next synchronisation.  A
+// context that has failed is torn down with ncclCommAbort instead of ncclCommDestroy.
 // Skewed shards (a top-byte bucket would not fit a rank): the split is redone at the 12-bit prefix (4096 bins, shard
 // ordered by its top two bytes); if that does not fit either, every rank returns GS_ERR_SIZE together.
 // RCCL is loaded lazily (dlopen "librccl.so.1") so that single-GPU users of libgpusort.so do not need it; tests
@@ -38,6 +52,10 @@ struct Rccl {
     int (*GroupStart)();
     int (*GroupEnd)();
     const char* (*GetErrorString)(int);
+    int (*CommSplit)(void* comm, int color, int key, void** newcomm, void* config);  // optional (NCCL >= 2.18)
+    int (*CommAbort)(void* comm);                                                     // optional
+    int (*AllToAllv)(const void* send, const size_t* sendcounts, const size_t* sdispls, void* recv, const size_t* recvcounts,
+                     const size_t* rdispls, int dtype, void* comm, hipStream_t s);    // optional (RCCL extension, rccl.h:815)
     bool ok;
 };
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3;  // ncclDataType_t (rccl.h:460-464)
@@ -60,6 +78,9 @@ Rccl* rccl() {
         GS_SYM(GroupStart, "ncclGroupStart");
         GS_SYM(GroupEnd, "ncclGroupEnd");
         GS_SYM(GetErrorString, "ncclGetErrorString");
+        GS_SYM(CommSplit, "ncclCommSplit");
+        GS_SYM(CommAbort, "ncclCommAbort");
+        GS_SYM(AllToAllv, "ncclAllToAllv");
 #undef GS_SYM
         x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.Send && x.Recv && x.GroupStart && x.GroupEnd;
         return x;
@@ -72,6 +93,7 @@ thread_local int g_last_rccl_error = 0;
 struct RcclTransport {
     void* comm;
     uint32_t rank, world;
+    int alltoallv;  // exchange through ncclAllToAllv instead of grouped send / recv (GPUSORT_MGPU_ALLTOALLV)
 };
 
 int rccl_all_gather_u32(void* user, const void* d_send, void* d_recv, size_t count, void* stream) {
@@ -97,6 +119,22 @@ int rccl_exchange(void* user, uint32_t n_arrays, const void* const* d_send, void
             return -1;
     }
     if (t->world == 1) return 0;
+    if (t->alltoallv && r->AllToAllv) {  // one call per array; counts and displacements in bytes (the own bucket went by copy)
+        std::vector<size_t> sc(t->world), sd(t->world), rc(t->world), rd(t->world);
+        int e = 0;
+        for (uint32_t a = 0; a < n_arrays && !e; ++a) {
+            const size_t eb = elem_bytes[a];
+            for (uint32_t p = 0; p < t->world; ++p) {
+                sc[p] = p == t->rank ? 0 : (size_t)send_counts[p] * eb;
+                rc[p] = p == t->rank ? 0 : (size_t)recv_counts[p] * eb;
+                sd[p] = (size_t)send_displs[p] * eb;
+                rd[p] = (size_t)recv_displs[p] * eb;
+            }
+            e = r->AllToAllv(d_send[a], sc.data(), sd.data(), d_recv[a], rc.data(), rd.data(), kNcclUint8, t->comm, s);
+        }
+        if (e) g_last_rccl_error = e;
+        return e;
+    }
     int e = r->GroupStart();
     for (uint32_t a = 0; a < n_arrays && !e; ++a) {
         const size_t eb = elem_bytes[a];
@@ -123,7 +161,16 @@ struct gs_mgpu {
     gs_onesweep* sorter;       // local engine: scan state for `capacity` keys
     gs_mgpu_transport transport;
     RcclTransport rccl_state;  // when the transport is RCCL
+    RcclTransport rccl_state2; // ... and the second communicator (values), if ncclCommSplit exists
+    gs_mgpu_transport transport2;  // the transport the values travel on (== transport without a second communicator)
     bool owns_comm;
+    hipStream_t s2;            // second stream: the value exchange and the closing status gather
+    hipEvent_t ev_part, ev_vals, ev_tail;
+    uint32_t *d_status;        // [0] this rank's status of the running call, [1 .. world] every rank's (gathered)
+    uint32_t* h_status;        // pinned mirror
+    int overlap;               // values on the second stream (GPUSORT_MGPU_OVERLAP, default 1)
+    int failed;                // a call on this context has failed: destroy aborts the communicators
+    int debug_fail;            // test hook: 1 = fail before the gather, 2 = fail after the plan (next call only)
     uint32_t *part_keys;       // shard grouped by destination; alt buffer of the local sort afterwards
     void* part_vals;
     uint32_t *d_hist, *d_table, *d_plan;  // nbins, world x nbins, plan words
@@ -148,6 +195,13 @@ gs_status mgpu_alloc(gs_mgpu* c) {
     GS_HIP(hipHostMalloc(&c->h_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipHostMallocDefault));
     GS_HIP(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
     for (auto& e : c->ev) GS_HIP(hipEventCreate(&e));
+    GS_HIP(hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking));
+    GS_HIP(hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&c->ev_vals, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    GS_HIP(hipMalloc(&c->d_status, (c->world + 1) * sizeof(uint32_t)));
+    GS_HIP(hipMemset(c->d_status, 0, (c->world + 1) * sizeof(uint32_t)));
+    GS_HIP(hipHostMalloc(&c->h_status, (c->world + 1) * sizeof(uint32_t), hipHostMallocDefault));
     return GS_OK;
 }
 
@@ -163,6 +217,8 @@ gs_status mgpu_new(gs_mgpu** out, uint32_t rank, uint32_t world, uint32_t shard_
     c->mode = mode; c->value_bytes = mode == GS_MODE_PAIRS ? value_bytes : 0;
     c->force_exchange = 0;
     if (const char* env = getenv("GPUSORT_MGPU_FORCE_EXCHANGE")) c->force_exchange = atoi(env) ? 1 : 0;
+    c->overlap = 1;
+    if (const char* env = getenv("GPUSORT_MGPU_OVERLAP")) c->overlap = atoi(env) ? 1 : 0;
     gs_status st = gs_onesweep_create(&c->sorter, capacity, mode, value_bytes);
     if (st == GS_OK) st = mgpu_alloc(c);
     if (st != GS_OK) { gs_mgpu_destroy(c); return st; }
@@ -171,15 +227,28 @@ gs_status mgpu_new(gs_mgpu** out, uint32_t rank, uint32_t world, uint32_t shard_
 }
 
 // steps 1-4 for one granularity: histogram of the shard -> gathered table -> plan on the host.  fine = 12-bit prefix.
-gs_status mgpu_plan(gs_mgpu* c, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, bool fine, PassPlan* pp) {
+// A rank whose own part fails (n == 0 shards have none) still gathers — a poisoned row — so that nobody waits for it; the
+// plan of every rank then says PLAN_PEER_FAILED.  *local = the rank's own error, if any.
+gs_status mgpu_plan(gs_mgpu* c, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, bool fine, PassPlan* pp, gs_status* local) {
     gs_onesweep* h = c->sorter;
     const uint32_t nbins = fine ? 4096u : gs::RADIX;
-    gs_status st = fine ? prologue(h, d_keys, n, kt, s, 2, 2, pp) : prologue(h, d_keys, n, kt, s, 3, 1, pp);
-    if (st != GS_OK) return st;
-    hipLaunchKernelGGL(gs::msd_fold_kernel, dim3(nbins / 256), dim3(256), 0, s, h->slab + SLAB_HIST, nbins, c->d_hist);
-    if (fine) {  // no pass follows this prologue: hand HIST back zeroed
-        GS_HIP(zero_hist(h, s));
-        h->hist_dirty = false;
+    gs_status st = GS_OK;
+    if (c->debug_fail == 1) st = GS_ERR_HIP;  // test hook: as if the histogram launch had failed
+    if (st == GS_OK && n) st = fine ? prologue(h, d_keys, n, kt, s, 2, 2, pp) : prologue(h, d_keys, n, kt, s, 3, 1, pp);
+    if (st == GS_OK && n) {
+        hipLaunchKernelGGL(gs::msd_fold_kernel, dim3(nbins / 256), dim3(256), 0, s, h->slab + SLAB_HIST, nbins, c->d_hist);
+        if (fine) {  // no pass follows this prologue: hand HIST back zeroed
+            if (zero_hist(h, s) != hipSuccess) st = GS_ERR_HIP;
+            h->hist_dirty = false;
+        }
+    } else if (st == GS_OK) {
+        if (hipMemsetAsync(c->d_hist, 0, 4096 * sizeof(uint32_t), s) != hipSuccess) st = GS_ERR_HIP;
+    }
+    if (st != GS_OK) {  // poison the row: every rank's plan will say so
+        *local = st;
+        static const uint32_t poison = gs::MSD_POISON;
+        (void)hipMemsetAsync(c->d_hist, 0, 4096 * sizeof(uint32_t), s);
+        (void)hipMemcpyAsync(c->d_hist, &poison, sizeof(uint32_t), hipMemcpyHostToDevice, s);
     }
     if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, nbins, s) != 0) return GS_ERR_COMM;
     hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, nbins, c->world, c->rank, c->capacity, c->d_plan);
@@ -224,9 +293,22 @@ gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES
         *out = nullptr;
         return GS_ERR_COMM;
     }
-    c->rccl_state = RcclTransport{comm, rank, world};
+    const int a2av = getenv("GPUSORT_MGPU_ALLTOALLV") ? atoi(getenv("GPUSORT_MGPU_ALLTOALLV")) : 0;
+    c->rccl_state = RcclTransport{comm, rank, world, a2av};
     c->owns_comm = true;
     c->transport = gs_mgpu_transport{&c->rccl_state, rccl_all_gather_u32, rccl_exchange};
+    c->transport2 = c->transport;
+    c->rccl_state2 = RcclTransport{nullptr, rank, world, a2av};
+    if (world > 1 && c->value_bytes && c->overlap && r->CommSplit) {  // collective: the values' own communicator
+        void* comm2 = nullptr;
+        const int e2 = r->CommSplit(comm, 0, (int)rank, &comm2, nullptr);
+        if (e2 == 0 && comm2) {
+            c->rccl_state2.comm = comm2;
+            c->transport2 = gs_mgpu_transport{&c->rccl_state2, rccl_all_gather_u32, rccl_exchange};
+        } else {
+            g_last_rccl_error = e2;  // not fatal: keys and values share the first communicator, one after the other
+        }
+    }
     return GS_OK;
 }
 
@@ -236,13 +318,29 @@ gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* 
     gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes);
     if (st != GS_OK) return st;
     (*out)->transport = *t;
+    (*out)->transport2 = *t;
     (*out)->owns_comm = false;
     return GS_OK;
 }
 
 gs_status gs_mgpu_destroy(gs_mgpu* c) {
     if (!c) return GS_ERR_ARG;
-    if (c->owns_comm && c->rccl_state.comm && rccl()) (void)rccl()->CommDestroy(c->rccl_state.comm);
+    if (c->owns_comm && rccl()) {
+        // a context that has failed may have collectives in flight that will never complete: abort, do not drain
+        auto drop = [&](void* comm) {
+            if (!comm) return;
+            if (c->failed && rccl()->CommAbort) (void)rccl()->CommAbort(comm);
+            else (void)rccl()->CommDestroy(comm);
+        };
+        drop(c->rccl_state2.comm);
+        drop(c->rccl_state.comm);
+    }
+    if (c->s2) (void)hipStreamDestroy(c->s2);
+    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
+    if (c->ev_vals) (void)hipEventDestroy(c->ev_vals);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->sorter) (void)gs_onesweep_destroy(c->sorter);
     if (c->part_keys) (void)hipFree(c->part_keys);
     if (c->part_vals) (void)hipFree(c->part_vals);
@@ -288,6 +386,8 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
     c->last_fine = 0;
     GS_HIP(hipEventRecord(c->ev[0], s));
     uint32_t n_recv = n;
+    hipEvent_t values_ready = nullptr;  // pairs with the values on the second stream: the local sort's passes wait for it
+    gs_status local = GS_OK;            // this rank's own error after the plan: reported to the peers, returned at the end
     if (c->world == 1 && !c->force_exchange) {
         if (n) GS_HIP(hipMemcpyAsync(d_out_keys, d_keys, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         if (n && vb) GS_HIP(hipMemcpyAsync(d_out_vals, d_vals, (size_t)n * vb, hipMemcpyDeviceToDevice, s));
@@ -298,33 +398,25 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         // contributes a zero histogram directly.
         PassPlan pp{};
         bool fine = false;
-        if (n == 0) {
-            GS_HIP(hipMemsetAsync(c->d_hist, 0, 4096 * sizeof(uint32_t), s));
-            if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, gs::RADIX, s) != 0) return GS_ERR_COMM;
-            hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, gs::RADIX, c->world, c->rank, c->capacity, c->d_plan);
-            GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            GS_HIP(hipEventRecord(c->ev_plan, s));
-            GS_HIP(hipEventSynchronize(c->ev_plan));
-        } else {
-            gs_status st = mgpu_plan(c, d_keys, n, kt, s, false, &pp);
-            if (st != GS_OK) return st;
-        }
-        if (c->h_plan[gs::PLAN_OVERFLOW]) {
+        gs_status early = GS_OK;  // this rank's own error BEFORE the gather: its row is poisoned, everybody stops together
+        gs_status st = mgpu_plan(c, d_keys, n, kt, s, false, &pp, &early);
+        if (st != GS_OK) { c->failed = 1; return st; }
+        if (!c->h_plan[gs::PLAN_PEER_FAILED] && c->h_plan[gs::PLAN_OVERFLOW]) {
             // every rank sees the same gathered table and takes the same decision: split at the 12-bit prefix
             fine = true;
-            if (n) {  // the top-byte scan state is abandoned: its histogram region must be handed back zeroed
-                GS_HIP(zero_hist(h, s));
+            if (n && early == GS_OK) {  // the top-byte scan state is abandoned: its histogram region must be handed back zeroed
+                if (zero_hist(h, s) != hipSuccess) early = GS_ERR_HIP;
                 h->hist_dirty = false;
-                gs_status st = mgpu_plan(c, d_keys, n, kt, s, true, &pp);
-                if (st != GS_OK) return st;
-            } else {
-                if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, 4096, s) != 0) return GS_ERR_COMM;
-                hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, 4096u, c->world, c->rank, c->capacity, c->d_plan);
-                GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                GS_HIP(hipEventRecord(c->ev_plan, s));
-                GS_HIP(hipEventSynchronize(c->ev_plan));
             }
-            if (c->h_plan[gs::PLAN_OVERFLOW]) return GS_ERR_SIZE;  // on every rank alike: raise the capacity
+            st = mgpu_plan(c, d_keys, n, kt, s, true, &pp, &early);
+            if (st != GS_OK) { c->failed = 1; return st; }
+            if (!c->h_plan[gs::PLAN_PEER_FAILED] && c->h_plan[gs::PLAN_OVERFLOW]) return GS_ERR_SIZE;  // on every rank alike: raise the capacity
+        }
+        if (c->h_plan[gs::PLAN_PEER_FAILED]) {  // on every rank alike: nobody enters the exchange
+            c->debug_fail = 0;
+            c->failed = 1;
+            if (n && h->hist_dirty) { (void)zero_hist(h, s); h->hist_dirty = false; }
+            return early != GS_OK ? early : GS_ERR_COMM;
         }
         c->last_fine = fine ? 1u : 0u;
         const uint32_t W = c->world;
@@ -332,24 +424,27 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         const uint32_t* recv = send + W;
         n_recv = c->h_plan[gs::PLAN_NRECV];
         if (n_recv > c->capacity) return GS_ERR_SIZE;
+        // ---- from here on the peers are committed to the exchange: an error of this rank is carried through it ----
+        if (c->debug_fail == 2) local = GS_ERR_HIP;  // test hook: as if the partition pass had failed to launch
+        c->debug_fail = 0;
         // group the shard by destination (stable)
-        if (n) {
+        if (n && local == GS_OK) {
             const BinLauncher fn = g_shapes[h->shape].fn[h->rank_mode][vb_index(vb)][kt];
-            if (!fn) return GS_ERR_ARG;
-            if (!fine) {
+            if (!fn) {
+                local = GS_ERR_ARG;
+            } else if (!fine) {
                 fn(s, pp.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys)), c->part_keys, const_cast<void*>(d_vals),
                    c->part_vals, h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB,
                    h->slab + SLAB_STATUS, n, 24, 4u);
-                GS_HIP(hipGetLastError());
+                if (hipGetLastError() != hipSuccess) local = GS_ERR_HIP;
                 h->hist_dirty = false;
             } else {  // order by the top two bytes: every 12-bit prefix range is contiguous (the output buffers are the scratch)
-                gs_status st = gs_onesweep_digit_pass(h, d_keys, d_out_keys, d_vals, d_out_vals, n, 2, kt, 0, s);
-                if (st == GS_OK) st = gs_onesweep_digit_pass(h, d_out_keys, c->part_keys, d_out_vals, c->part_vals, n, 3, kt, 0, s);
-                if (st != GS_OK) return st;
+                local = gs_onesweep_digit_pass(h, d_keys, d_out_keys, d_vals, d_out_vals, n, 2, kt, 0, s);
+                if (local == GS_OK) local = gs_onesweep_digit_pass(h, d_out_keys, c->part_keys, d_out_vals, c->part_vals, n, 3, kt, 0, s);
             }
         }
         GS_HIP(hipEventRecord(c->ev[1], s));
-        // bucket exchange: keys and values in one group
+        // bucket exchange
         std::vector<uint32_t> sd(W), rd(W);
         uint32_t a = 0, b = 0;
         for (uint32_t p = 0; p < W; ++p) {
@@ -360,18 +455,66 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         const void* src[2] = {c->part_keys, c->part_vals};
         void* dst[2] = {d_out_keys, d_out_vals};
         const uint32_t eb[2] = {4u, vb};
-        if (c->transport.exchange(c->transport.user, vb ? 2u : 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) return GS_ERR_COMM;
+        hipStream_t tail = s;  // the stream the closing status gather goes on
+        if (vb && c->overlap) {
+            // keys on the caller's stream; values on the second stream (and the second communicator) behind the partition pass
+            if (hipEventRecord(c->ev_part, s) != hipSuccess || hipStreamWaitEvent(c->s2, c->ev_part, 0) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
+            if (c->transport.exchange(c->transport.user, 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) { c->failed = 1; return GS_ERR_COMM; }
+            if (c->transport2.exchange(c->transport2.user, 1u, src + 1, dst + 1, eb + 1, send, sd.data(), recv, rd.data(), c->s2) != 0) { c->failed = 1; return GS_ERR_COMM; }
+            if (hipEventRecord(c->ev_vals, c->s2) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
+            values_ready = c->ev_vals;
+            tail = c->s2;
+        } else if (c->transport.exchange(c->transport.user, vb ? 2u : 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) {
+            c->failed = 1;
+            return GS_ERR_COMM;
+        }
         GS_HIP(hipEventRecord(c->ev[2], s));
+        // closing status gather: every rank learns whether some peer carried an error through the exchange
+        c->h_status[0] = (uint32_t)local;
+        if (hipMemcpyAsync(c->d_status, c->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, tail) != hipSuccess ||
+            (vb && c->overlap ? c->transport2 : c->transport).all_gather_u32((vb && c->overlap ? c->transport2 : c->transport).user,
+                                                                             c->d_status, c->d_status + 1, 1, tail) != 0) {
+            c->failed = 1;
+            return GS_ERR_COMM;
+        }
+        if (tail != s) {  // the caller's stream must not run ahead of the side stream's last use of the context
+            if (hipEventRecord(c->ev_tail, tail) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
+        }
+        if (local != GS_OK) {  // the peers are served; this rank's own result is not there
+            if (tail != s) (void)hipStreamWaitEvent(s, c->ev_tail, 0);
+            c->failed = 1;
+            return local;
+        }
     }
     // local 4-pass sort of the received bucket; the partition buffers are free again and serve as alt
     if (n_recv) {
-        gs_status st = vb ? gs_onesweep_sort_pairs(h, d_out_keys, d_out_vals, c->part_keys, c->part_vals, n_recv, kt, GS_ORDER_ASCENDING, s)
+        gs_status st = vb ? sort_impl(h, d_out_keys, d_out_vals, c->part_keys, c->part_vals, n_recv, kt, GS_ORDER_ASCENDING, s, vb, values_ready)
                           : gs_onesweep_sort_keys(h, d_out_keys, c->part_keys, n_recv, kt, GS_ORDER_ASCENDING, s);
-        if (st != GS_OK) return st;
+        if (st != GS_OK) { c->failed = 1; return st; }
+    } else if (values_ready) {
+        GS_HIP(hipStreamWaitEvent(s, values_ready, 0));
     }
+    if (values_ready) GS_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));  // everything of the call is behind the caller's stream
     GS_HIP(hipEventRecord(c->ev[3], s));
     *out_n = n_recv;
     c->prof_pending = true;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_check(gs_mgpu* c, void* stream) {
+    if (!c) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GS_HIP(hipMemcpyAsync(c->h_status, c->d_status, (c->world + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    if (c->world > 1 || c->force_exchange)
+        for (uint32_t r = 0; r < c->world; ++r)
+            if (c->h_status[1 + r] != GS_OK) { c->failed = 1; return GS_ERR_COMM; }  // a peer carried an error through the exchange
+    return gs_onesweep_check(c->sorter, stream);
+}
+
+gs_status gs_mgpu_debug_fail(gs_mgpu* c, int where) {
+    if (!c || where < 0 || where > 2) return GS_ERR_ARG;
+    c->debug_fail = where;
     return GS_OK;
 }
 

@@ -12,6 +12,8 @@ namespace gs {
 constexpr uint32_t PLAN_NRECV = 0;      // keys this rank receives
 constexpr uint32_t PLAN_OVERFLOW = 1;   // != 0: some rank's bucket exceeds `capacity`
 constexpr uint32_t PLAN_MAXBUCKET = 2;  // largest bucket (saturated to 2^32-1)
+constexpr uint32_t PLAN_PEER_FAILED = 3;  // != 0: some rank gathered a poisoned histogram row (it failed before the gather)
+constexpr uint32_t MSD_POISON = 0x80000000u;  // a count no shard can reach (n < 2^30): marks the row of a rank that has failed
 constexpr uint32_t PLAN_HEADER = 4;     // then send_counts[world], recv_counts[world], first_bin[world + 1]
 __host__ __device__ constexpr uint32_t plan_words(uint32_t world) { return PLAN_HEADER + 3 * world + 1; }
 constexpr uint32_t MSD_MAX_WORLD = 256;
@@ -54,8 +56,19 @@ __global__ __launch_bounds__(256) void msd_plan_kernel(const uint32_t* table, ui
     for (uint32_t i = tid; i < MSD_MAX_WORLD; i += 256) { s_bucket[i] = 0; s_send[i] = 0; s_recv[i] = 0; }
     // global histogram of my bins and its exclusive prefix
     unsigned long long mine = 0;
+    uint32_t poisoned = 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     for (uint32_t j = 0; j < per; ++j)
-        for (uint32_t r = 0; r < world; ++r) mine += table[(size_t)r * nbins + b0 + j];
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t c = table[(size_t)r * nbins + b0 + j];
+            poisoned |= c & MSD_POISON;
+            mine += c;
+        }
+    if (poisoned) atomicOr(&s_cnt, 1u);
+    __syncthreads();
+    const uint32_t peer_failed = s_cnt;
+    __syncthreads();
     const unsigned long long incl = wave_inclusive_scan_u64(mine, lane);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256) void msd_plan_kernel(const uint32_t* table, ui
         plan[PLAN_NRECV] = (uint32_t)(nrecv > 0xffffffffull ? 0xffffffffull : nrecv);
         plan[PLAN_OVERFLOW] = mx > capacity ? 1u : 0u;
         plan[PLAN_MAXBUCKET] = (uint32_t)(mx > 0xffffffffull ? 0xffffffffull : mx);
-        plan[3] = 0;
+        plan[PLAN_PEER_FAILED] = peer_failed;
     }
 }
 

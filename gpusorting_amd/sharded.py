@@ -250,6 +250,17 @@ class ShardedOneSweep:
         except Exception:  # noqa: BLE001
             pass
 
+    def check(self) -> None:
+        """gs_mgpu_check: synchronises and raises if the last call failed on ANY rank (a peer that failed on its own after the
+        plan has still served this rank's receives, and says so in the call's closing all-gather) or on the local sorter."""
+        from .onesweep import _stream_ptr
+        if self._ctx:
+            _lib.check(_lib.load().gs_mgpu_check(self._ctx, _stream_ptr()), "gs_mgpu_check")
+
+    def debug_fail(self, where: int) -> None:
+        """Test hook: this rank's next sort fails on its own (1: before the histogram gather, 2: after the plan)."""
+        _lib.check(_lib.load().gs_mgpu_debug_fail(self._ctx, int(where)), "gs_mgpu_debug_fail")
+
     def profile(self) -> dict:
         """Phase times (ms) and off-rank bytes of the last native sort on this rank."""
         ms = (C.c_float * 4)()

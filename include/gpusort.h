@@ -242,10 +242,22 @@ gs_status gs_mgpu_destroy(gs_mgpu* ctx);
  * d_vals) is this rank's shard (n may be 0; unchanged on return); d_out_keys / d_out_vals are caller-owned buffers
  * of `capacity` elements that receive this rank's contiguous range of the global result, *out_n its length.  Stable
  * (received order = source rank, source position).  Asynchronous on `stream` except for ONE wait on a few dozen
- * words (per-peer counts: RCCL's send/recv take them as host integers).  GS_ERR_SIZE on EVERY rank if a bucket does
- * not fit `capacity` even at 12-bit-prefix granularity. */
+ * words (per-peer counts: RCCL's send/recv take them as host integers).  Pairs: the values travel on a second stream and (RCCL)
+ * a second communicator behind the keys, and the local sort's GlobalHistogram + Scan run on the received keys meanwhile;
+ * GPUSORT_MGPU_OVERLAP=0 keeps keys and values in one group, GPUSORT_MGPU_ALLTOALLV=1 uses ncclAllToAllv instead of grouped
+ * send / recv (both read at gs_mgpu_create).  GS_ERR_SIZE on EVERY rank if a bucket does not fit `capacity` even at
+ * 12-bit-prefix granularity; GS_ERR_COMM on every rank if some rank failed before the histogram gather (see gs_mgpu_check for
+ * failures after it). */
 gs_status gs_onesweep_sort_sharded(gs_mgpu* ctx, const void* d_keys, const void* d_vals, uint32_t n, gs_key_type key_type,
                                    void* d_out_keys, void* d_out_vals, uint32_t* out_n, void* stream);
+/* Synchronises `stream` and reports the last call's outcome: GS_ERR_COMM if SOME rank carried an error of its own through the
+ * exchange (every rank's status is all-gathered at the end of the call: its peers were served, its own result is not there, and
+ * the global result is incomplete), otherwise gs_onesweep_check() of the local sorter.  (A rank that fails BEFORE the histogram
+ * gather poisons its row instead, and every rank's gs_onesweep_sort_sharded returns GS_ERR_COMM at once.) */
+gs_status gs_mgpu_check(gs_mgpu* ctx, void* stream);
+/* Test hook: the next gs_onesweep_sort_sharded on this rank fails on its own — 1: before the histogram gather, 2: after the plan
+ * (as if a HIP launch had failed) — to exercise the failure agreement with the peers.  0 clears it. */
+gs_status gs_mgpu_debug_fail(gs_mgpu* ctx, int where);
 /* Phase times of the last gs_onesweep_sort_sharded on this rank (HIP events on its stream; synchronises):
  * ms[0] split (histogram + all-gather + plan + the host wait + partition pass), ms[1] bucket exchange,
  * ms[2] local sort, ms[3] total; bytes this rank sent to / received from OTHER ranks; whether the 12-bit split ran. */

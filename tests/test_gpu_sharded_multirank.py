@@ -41,7 +41,7 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     s = ShardedOneSweep(shard, slack=slack, pairs=pairs, value_bytes=4)   # the C++ pipeline (gs_onesweep_sort_sharded) over a host-staged transport
     bk, bv, nb = s.sort(keys, values=vals)
     torch.cuda.synchronize()
-    s.engine.sorter.check()
+    s.check()   # gs_mgpu_check: no rank carried an error through the exchange, the local sorter is clean
     assert s.last_split == ("12-bit prefix" if andc < 0 else "top byte"), s.last_split
     q.put((rank, k0, v0, bk.cpu().numpy().view(np.uint32).copy(), None if bv is None else bv.cpu().numpy().view(np.uint32).copy()))
     dist.barrier()
@@ -80,3 +80,71 @@ def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
     for a, b in zip(got[:-1], got[1:]):              # buckets are contiguous ranges of the global order
         if a[3].size and b[3].size:
             assert a[3].max() <= b[3].min()
+
+
+def _failing_worker(rank, world, port, shard, where, pairs, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import gpusorting_amd as g
+    from gpusorting_amd import _lib
+    from gpusorting_amd.sharded import ShardedOneSweep
+    torch.cuda.set_device(0)
+    keys = torch.empty(shard, dtype=torch.int32, device="cuda")
+    g.init_random(keys, 10 + 1000 * rank, 0)
+    vals = torch.arange(shard, dtype=torch.int32, device="cuda") if pairs else None
+    s = ShardedOneSweep(shard, slack=3.0, pairs=pairs, value_bytes=4)
+    if rank == world - 1:
+        s.debug_fail(where)            # this rank fails on its own in the next call
+    outcome = []
+    try:
+        s.sort(keys, values=vals)
+        outcome.append("sort-ok")
+    except _lib.GpuSortError as e:
+        outcome.append(f"sort-status-{e.status}")
+    try:
+        s.check()
+        outcome.append("check-ok")
+    except _lib.GpuSortError as e:
+        outcome.append(f"check-status-{e.status}")
+    # the context is still usable after a failure that everybody saw: a second, healthy call sorts
+    bk, _, nb = s.sort(keys, values=vals)
+    s.check()
+    ok = bool((bk[1:nb].to(torch.int64) & 0xFFFFFFFF >= bk[:nb - 1].to(torch.int64) & 0xFFFFFFFF).all().item()) if nb > 1 else True
+    total = torch.tensor([nb], dtype=torch.int64)
+    dist.all_reduce(total)
+    q.put((rank, outcome, ok and int(total.item()) == shard * world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where,pairs", [(1, False), (2, False), (2, True)])
+def test_a_rank_that_fails_alone_does_not_strand_its_peers(gpu, where, pairs):
+    """Round-2 review, multi-GPU item (c): a rank that fails alone — before the histogram gather (where = 1) or after the plan
+    (where = 2: the peers are already committed to the exchange) — must not leave the others inside a collective.  Two ranks on
+    one GPU over the host-staged transport; the last rank fails.  where = 1: its row of the gather is poisoned, EVERY rank's
+    sort returns at once (the failing one with its own error, the other with GS_ERR_COMM).  where = 2: the failing rank still
+    serves the exchange and reports in the closing status gather: its own sort returns GS_ERR_HIP, the peer's sort returns
+    GS_OK and its gs_mgpu_check says GS_ERR_COMM.  Nobody hangs, and the next call on the same contexts sorts."""
+    from gpusorting_amd import _lib
+    world, shard = 2, (1 << 18) + 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, shard, where, pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    healthy, failing = got[0][1], got[1][1]
+    if where == 1:
+        assert healthy[0] == f"sort-status-{_lib.GS_ERR_COMM}", got
+        assert failing[0] == f"sort-status-{_lib.GS_ERR_HIP}", got
+    else:
+        assert healthy == ["sort-ok", f"check-status-{_lib.GS_ERR_COMM}"], got
+        assert failing[0] == f"sort-status-{_lib.GS_ERR_HIP}", got
+    assert got[0][2] and got[1][2], got   # the follow-up call on the same contexts is exact in size and sorted

@@ -59,3 +59,20 @@ def test_rocprim_comparator_sorts_and_agrees_elementwise(tools):
     assert rc == 0, out[-2000:]
     assert out.count("sorted=yes") == 2, out
     print(out)
+
+
+@pytest.mark.parametrize("mode,pairs", [("fork", 0), ("threads", 4)])
+def test_torch_free_multi_gpu_harness_on_one_gpu(tools, mode, pairs):
+    """tools/mgpu_main.cpp (round-2 review, multi-GPU item (a)): one rank per GPU over the C-ABI, no Python —
+    here with ONE rank whose exchange path is forced, in both process models (fork: one process per GPU with the communicator id
+    handed through pipes; threads: the ncclCommInitAll model).  The JSON line must verify (sorted, sizes add up) and carry the
+    phase times, the link figures and the local sort's roofline; with 8 GPUs the same binary runs `--gpus 8`."""
+    import json
+    rc, out = _run([os.path.join(tools, "mgpu_main"), "--gpus", "1", "--log2", "24", "--iters", "3", "--mode", mode, "--pairs", str(pairs)])
+    assert rc == 0, out[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["verified"] is True and d["n_gpus"] == 1 and d["mode"] == mode and d["value_bytes"] == pairs, d
+    assert d["value"] > 1.0 and d["phase_ms_max_over_ranks"]["local_sort"] > 0.0, d
+    assert 0.0 < d["local_sort_rank0"]["roofline"]["frac"] < 1.0, d
+    assert d["rank_exit_codes"] == [0], d
