@@ -160,6 +160,7 @@ struct gs_onesweep {
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
+    uint32_t* partials;  // the histogram workgroups' tables: hist_blocks(max_keys) x HIST_TABLE_WORDS, summed by hist_reduce_kernel
     int profiling;
     hipEvent_t ev[GS_PROFILE_SLOTS + 1];
     bool ev_valid;
@@ -182,12 +183,16 @@ size_t slab_words_for(uint32_t max_keys) {
     return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
 }
 
-using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                              uint32_t*);
 template <int KT>
 void launch_hist(hipStream_t s, uint32_t blocks, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n,
-                 uint32_t seg_len0, uint32_t p0, uint32_t np, uint32_t word, uint32_t allow_pos) {
+                 uint32_t seg_len0, uint32_t p0, uint32_t np, uint32_t word, uint32_t allow_pos, uint32_t* partials) {
     hipLaunchKernelGGL((gs::global_histogram_kernel<KT>), dim3(blocks), dim3(gs::GHIST_THREADS), 0, s, keys, slab,
-                       used_words, n, seg_len0, p0, np, word, allow_pos);
+                       used_words, n, seg_len0, p0, np, word, allow_pos, partials);
+    // the workgroups' tables -> the HIST region (one thread per bin)
+    hipLaunchKernelGGL(gs::hist_reduce_kernel, dim3(np * gs::NCH * gs::RADIX / 64u), dim3(256), 0, s, partials, blocks,
+                       np * gs::NCH * gs::RADIX, slab + SLAB_HIST);
 }
 inline hipError_t zero_hist(gs_onesweep* h, hipStream_t s) {  // the HIST region: four joint tables + what the keys look like as a whole
     return hipMemsetAsync(h->slab + SLAB_HIST, 0, gs::HIST_WORDS * sizeof(uint32_t), s);
@@ -225,6 +230,15 @@ uint32_t pos_grid() {
     return 2u * cus;
 }
 
+// most workgroups the histogram kernel is ever launched with for a handle of max_keys keys (sizes its slices)
+uint32_t hist_blocks_cap(uint32_t max_keys) {
+    uint32_t m = hist_blocks(max_keys);
+    if (max_keys > (1u << 22)) { const uint32_t b = hist_blocks(1u << 22); m = b > m ? b : m; }
+    static const int forced = getenv("GPUSORT_HIST_BLOCKS") ? atoi(getenv("GPUSORT_HIST_BLOCKS")) : 0;
+    if (forced > 0 && (uint32_t)forced > m) m = (uint32_t)forced;
+    return m;
+}
+
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 // Clears the scan state and runs GlobalHistogram + Scan for passes p0 .. p0+np-1
@@ -255,7 +269,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (rec) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
     g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
-               (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u);
+               (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u, h->partials);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
@@ -488,7 +502,9 @@ const char* gs_status_string(gs_status s) {
 
 int gs_last_hip_error(void) { return g_last_hip_error; }
 
-size_t gs_onesweep_temp_bytes(uint32_t max_keys) { return slab_words_for(max_keys) * sizeof(uint32_t); }
+size_t gs_onesweep_temp_bytes(uint32_t max_keys) {
+    return (slab_words_for(max_keys) + (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS) * sizeof(uint32_t);
+}
 
 uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes) {
     const Shape& sh = g_shapes[(mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0];
@@ -554,13 +570,16 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
             for (int i = 0; i < g_num_shapes; ++i)
                 if (g_shapes[i].threads == t && g_shapes[i].kpt == k) { h->shape = i; h->shape_auto = 0; }
     }
+    h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->partials, (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS * sizeof(uint32_t));
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
     if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_DESC * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         if (h->slab) (void)hipFree(h->slab);
+        if (h->partials) (void)hipFree(h->partials);
         delete h;
         return GS_ERR_HIP;
     }
@@ -574,6 +593,7 @@ gs_status gs_onesweep_destroy(gs_onesweep* h) {
         for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->slab) (void)hipFree(h->slab);
+    if (h->partials) (void)hipFree(h->partials);
     delete h;
     return GS_OK;
 }

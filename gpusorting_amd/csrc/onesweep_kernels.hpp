@@ -336,7 +336,9 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                                                                          uint32_t np, uint32_t word,
                                                                          uint32_t allow_pos /*1: the sort may run on position
                                                                          chains (scan_kernel, PF_POS) — uneven digit groups end the
-                                                                         counting of the joint tables*/) {
+                                                                         counting of the joint tables*/,
+                                                                         uint32_t* partials /*[gridDim][HIST_TABLE_WORDS]: every
+                                                                         workgroup's tables, summed by hist_reduce_kernel*/) {
     constexpr int KW = KeyWords<KT>::value;
     __shared__ uint32_t s_h[4 * NCH * RADIX];
     __shared__ uint32_t s_uneven;  // a digit group of this workgroup's first work item holds more than GS_POS_SHARE of its keys
@@ -562,13 +564,43 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #else
     __syncthreads();
 #endif
-    for (uint32_t i = tid; i < bins; i += GHIST_THREADS) {
-        const uint32_t v = s_h[i];
-        if (v) atomicAdd(&hist[i], v);
+    // The workgroup's tables go out as they are — coalesced plain stores into its own slice — and hist_reduce_kernel sums the
+    // slices.  (One global atomic per non-empty bin cost 256 workgroups x ~14 000 device-scope atomics on the same 16 384 words:
+    // 20-40 us of every sort from 2^23 keys up, half of this kernel at 2^23, profiles/r03_mid_size_routes.txt.)
+    {
+        uint32_t* mine = partials + (size_t)blockIdx.x * HIST_TABLE_WORDS;
+        for (uint32_t i = tid; i < bins / 4u; i += GHIST_THREADS)
+            reinterpret_cast<uint4*>(mine)[i] = reinterpret_cast<const uint4*>(s_h)[i];
     }
     // (measured: accumulating the OR / AND of all keys here, to drop constant bytes in position-chain sorts too, cost 0.08 ms)
     if (tid == 0 && joint_off) atomicOr(&hist[HIST_TABLE_WORDS + HX_SKEW], 1u);
     GS_ABL_CLOCKS_END();
+}
+
+// Sum of the histogram workgroups' tables: hist[i] = sum over workgroups of partials[w][i].  A workgroup of 256 threads owns
+// 64 consecutive bins; thread (g, b) = (tid / 64, tid % 64) sums every fourth slice of bin b — 256-byte wave loads, up to
+// 8 in flight, at most nblocks / 4 of them in a row — and the four partial sums meet in LDS.  (One thread per bin, 256 loads
+// in a row, was latency-bound: 30 us.)  The HIST region is overwritten, not accumulated into.
+__global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t* __restrict__ partials, uint32_t nblocks, uint32_t bins,
+                                                           uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_part[4][64];
+    const uint32_t b = threadIdx.x & 63u, g = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64u + b;
+    uint32_t acc = 0;
+    if (i < bins) {
+        uint32_t w = g;
+        for (; w + 28u < nblocks; w += 32u) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) v[j] = partials[(size_t)(w + 4u * j) * HIST_TABLE_WORDS + i];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; w < nblocks; w += 4u) acc += partials[(size_t)w * HIST_TABLE_WORDS + i];
+    }
+    s_part[g][b] = acc;
+    __syncthreads();
+    if (g == 0 && i < bins) hist[i] = s_part[0][b] + s_part[1][b] + s_part[2][b] + s_part[3][b];
 }
 
 // ---------------------------------------------------------------------------
