@@ -826,10 +826,12 @@ __device__ __forceinline__ void binning_body(
                     runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
                     on the last pass that runs (PF_LAST); bit2: zero the HIST region; bit4 / bit5: this launch is one of two
                     forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5); bit6: the
-                    pass is launched in BOTH chain forms — this one works only if the plan's PF_POS matches its POS*/) {
+                    pass is also launched in its position-chain form — this launch works only if the plan's PF_POS matches its POS
+                    (checked first)*/) {
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
-    static_assert(!POS || (VB == 0 && KW == 1 && RANK == 1), "the position-chain form exists for 32-bit keys-only sorts, LDS-atomic ranking");
+    static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || (VB == 8 && VR == 2))),
+                  "the position-chain forms exist for 32-bit keys, keys-only or with 8-byte values (two staging rounds), LDS-atomic ranking");
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
     constexpr uint32_t TILE = Cfg::TILE;
@@ -860,6 +862,10 @@ __device__ __forceinline__ void binning_body(
     if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
         const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
         if (skewed != ((mode & 16u) != 0u)) return;
+    }
+    if (mode & 64u) {  // the pass is launched in several forms: the plan says whether the position-chain form or the others work
+        const bool planned_pos = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) != 0;
+        if (planned_pos != (POS != 0)) return;
     }
     // ---- POS: what a workgroup of a position-chain pass sets up once.  Behind the first pass nobody knows the pass's digit
     // counts upfront: CNEXT[this pass][segment][digit], gathered by the pass that wrote this pass's input, is all there
@@ -1529,7 +1535,8 @@ __device__ __forceinline__ void binning_body(
             constexpr int J0 = 0, JN = KPT / VRN;  // this round's stage slots: tid + (h * JN + j) * THREADS
             if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
                 // (batches of 8 stage reads: with two rounds the other round's values are still in registers)
-                constexpr int VBATCH = VRN == 2 ? 8 : JN;
+                constexpr int VBATCH = VRN == 2 ? (JN % 8 == 0 ? 8 : 4) : JN;
+                static_assert(JN % VBATCH == 0, "value batches must tile a staging round");
 #pragma unroll
                 for (int j0 = J0; j0 < JN; j0 += VBATCH) {
                     V vv[VBATCH];
@@ -1600,6 +1607,19 @@ __global__ __launch_bounds__(512, 4) void digit_binning_dual_kernel(
     } else {
         binning_body<512, 24, 0, KT, 1, 1, 1, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
     }
+}
+
+// (u32 key, u64 value) pairs that the Scan kernel may plan on position chains: the position-chain form as a launch of its own
+// (persistent workgroups, values staged in two rounds through the keys' stage) beside the two plain forms, each of which exits
+// on the plan's flags (mode bit 6) — one kernel holding all three would need the one-round form's 140 KiB of LDS.
+template <int KT, bool LAST>
+__global__ __launch_bounds__(512, 4) void digit_binning_pos8_kernel(
+    uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
+    uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
+    constexpr int KPT = LAST ? 32 : 24, POS = LAST ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<512, KPT, 8, 1, 2, POS>::LDS_BYTES];
+    static_assert(sizeof(s_raw) * 2 <= 160 * 1024, "two workgroups per CU");
+    binning_body<512, KPT, 8, KT, 1, 2, POS, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
 }
 
 // ---------------------------------------------------------------------------
