@@ -105,6 +105,7 @@ gs_status gs_onesweep_sort_pairs(gs_onesweep* h, void* d_keys, void* d_vals, voi
  * GS_OK or GS_ERR_TIMEOUT.  With the look-back fallback of the default build (a tile that
  * waits too long recounts its predecessor itself) a timeout cannot occur; the word exists
  * for builds without it (-DGS_FALLBACK=0), whose bounded spins report here instead of hanging.
+ * Every sort resets the word itself, whatever route it takes.
  * (The reference checks nothing; D3D12 only warns, GPUSortingD3D12/SweepBase.h:52-53.) */
 gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
 
@@ -130,8 +131,9 @@ int gs_onesweep_get_rank_mode(gs_onesweep* h); /* the mode in use (after the cre
  * (tests use 0 to push small sizes through the tiled path as well). */
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
 /* Mid sizes (single-tile limit < n <= 2^20; keys-only and 4-byte values up to 2^21, keys-only up to 2^22; 32-bit keys) are
- * sorted in TWO launches instead of six: one MSD pass on the
- * top byte (all workgroups resident, one grid barrier) and one workgroup per top-byte bucket that sorts the remaining 24
+ * sorted in TWO launches instead of seven: one MSD pass on the
+ * top byte (its workgroups claim their tiles and adopt the tiles of workgroups that were never dispatched: no residency
+ * requirement) and one workgroup per top-byte bucket that sorts the remaining 24
  * bits in LDS; a top byte too skewed for that (a bucket above one tile: 8192 / 16 384 / 32 768 keys) is noticed on the device and the first kernel
  * runs the four LSD passes itself (reference size sweep GPUSortingD3D12/Tests.h:392-393,415-416).  Same
  * result either way; 0 sends these sizes through the general path.  Only used while the library picks the tile shape.

@@ -61,7 +61,7 @@ def test_2pow28_properties(gpu, pairs):
 @pytest.mark.parametrize("andc", [0, 4])
 def test_maximum_size_2pow30_minus_1(gpu, andc):
     """Largest n the API accepts (30-bit tile-descriptor payload): 4 GiB of keys, uniform and at entropy preset 5
-    (heavy-value slices with the largest possible counts).  Properties only: the reference's own pass criterion
+    (the position-chain plan with the largest possible counts).  Properties only: the reference's own pass criterion
     (no inversion) and all four digit histograms preserved."""
     import torch
     n = (1 << 30) - 1
@@ -105,7 +105,7 @@ def test_2pow24_typed_keys_exact(gpu, oracle, kt, order, vb):
 @pytest.mark.parametrize("andc,pairs", [(4, False), (3, False), (2, False), (4, True)])
 def test_2pow28_low_entropy_properties(gpu, andc, pairs):
     """BASELINE configs[4]'s entropy presets at full size (presets 3-5): skewed ranking, and for keys-only
-    sorts the heavy-value position slices, on 16 384 tiles.  Properties: no inversion, permutation-invariant
+    sorts on the position-chain plan (12 288-key counting tiles, 16 384-key last pass).  Properties: no inversion, permutation-invariant
     checksums, all digit histograms preserved, payload travelled with its key."""
     import torch
     n = 1 << 28
@@ -164,7 +164,7 @@ def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0):
 
 @pytest.mark.parametrize("andc", [0, 4])
 def test_2pow28_keys_exact_vs_oracle(gpu, oracle, andc):
-    """configs[1] bit-exact at full size; preset 5 runs the heavy-value position slices at their default
+    """configs[1] bit-exact at full size; preset 5 runs the position-chain plan at its default
     threshold (n >= 2^26, a value holding > n/2 keys)."""
     _exact_case(gpu, oracle, 28, andc, 0)
 
