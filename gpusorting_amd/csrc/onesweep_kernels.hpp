@@ -1461,7 +1461,12 @@ __device__ __forceinline__ void binning_body(
         }
     } else if (GS_LIKELY(full) && !GS_ABL_GENERIC_SCATTER) {
         // the common case as straight-line code: all stage reads first, then the base look-ups, then the stores
-        // (with the masks and the reversal in the loop every key got its own branches and LDS round trips)
+        // (with the masks and the reversal in the loop every key got its own branches and LDS round trips).
+        // Measured in round 3 and not kept: a RUN-aligned scatter — every wave walks the runs of its 32 digits, one store
+        // instruction per 256-byte-aligned window of the output, so that no instruction ends inside a 64-byte chunk (the
+        // slot-ordered loop cuts every run once more than its misalignment does: +0.94 of 4 L2 write requests per run,
+        // DESIGN.md 0).  Exact, and 0.47 -> 0.58 ms per pass: ~65 dependent (readlane, LDS read, store) steps per wave
+        // instead of 32 + 32 independent ones (profiles/r03_ab_run_aligned_scatter.txt).
         if constexpr (KW == 2) {
             uint2 kb[KPT];
 #pragma unroll
