@@ -71,6 +71,12 @@ def _assert_scan_state(s, n):
     chain, every chain's tickets >= its tiles, the histogram region handed back zeroed, and every pass that ran
     accounts for exactly n keys (a dropped identity pass for none) — cf. UtilityKernels.cuh:482-502."""
     r = s.check_state()
+    if "fault" in os.path.basename(os.environ.get("GPUSORT_LIB", "")):
+        # fault-injection builds (tools/r03_run25.sh: the fuzz sweep under libgpusort_fault.so): one tile per pass never publishes
+        # its rows — its successors' recount leaves them REDUCTION (a tile count, below the inclusive count in front of it) —
+        # so only the ticket and histogram invariants hold
+        assert r["chains_short_of_tickets"] == 0 and r["hist_words_nonzero"] == 0, r
+        return
     assert r["rows_not_inclusive"] == 0 and r["rows_not_monotone"] == 0, r
     assert r["chains_short_of_tickets"] == 0 and r["hist_words_nonzero"] == 0, r
     assert all(k in (0, n) for k in r["keys_per_pass"]), (n, r)
