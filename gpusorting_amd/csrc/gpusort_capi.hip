@@ -333,34 +333,38 @@ inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_k
 #endif
 }
 
-// mid sizes: two launches (mid_kernels.hpp).  [tile class][rank mode][vb index][key type]; tile classes: 8192 keys
-// (n <= 2^20, every value width), 16 384 (n <= 2^21, keys-only and 4-byte values), 32 768 (n <= 2^22, keys-only)
+// mid sizes: two launches (mid_kernels.hpp).  [class][rank mode][vb index][key type]; classes by the bucket K2 can hold:
+// 8192 keys (n <= 2^20, every value width; K1: <= 128 tiles of 8192), 16 384 (n <= 2^21, keys-only and 4-byte values; K1: <= 128
+// tiles of 16 384), 32 768 (n <= 2^22, keys-only; K1: <= 256 tiles of 16 384 — the 32 768-key tile spilled there and kept
+// half the CUs idle, 44 us of a 67 us sort, profiles/r03_mid_size_timeline.txt)
 using MidLauncher = void (*)(hipStream_t, uint32_t n_tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch,
                              uint32_t* status, uint32_t n, uint32_t descending);
-template <int VB, int KT, int RANK, int T, int K>
+template <int VB, int KT, int RANK, int T, int K, int T2 = T, int K2 = K>
 void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, void* vals, void* valt, uint32_t* scratch, uint32_t* status,
                 uint32_t n, uint32_t descending) {
-    hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK, T, K>), dim3(tiles), dim3(T), 0, s, keys, alt, vals, valt, scratch, status, n,
-                       descending);
-    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T, K>), dim3(gs::RADIX), dim3(T), 0, s, keys, alt, vals, valt, scratch, status,
+    hipLaunchKernelGGL((gs::mid_msd_kernel<VB, KT, RANK, T, K, T2 * K2>), dim3(tiles), dim3(T), 0, s, keys, alt, vals, valt, scratch, status,
                        n, descending);
+    hipLaunchKernelGGL((gs::bucket_sort_kernel<VB, KT, RANK, T2, K2>), dim3(gs::RADIX), dim3(T2), 0, s, keys, alt, vals, valt, scratch,
+                       status, n, descending);
 }
 #ifndef GS_MINIMAL
-#define GS_MID_ROW(VB, R, T, K) {launch_mid<VB, 0, R, T, K>, launch_mid<VB, 1, R, T, K>, launch_mid<VB, 2, R, T, K>}
+#define GS_MID_ROW(VB, R, ...) {launch_mid<VB, 0, R, __VA_ARGS__>, launch_mid<VB, 1, R, __VA_ARGS__>, launch_mid<VB, 2, R, __VA_ARGS__>}
 #define GS_MID_NONE {nullptr, nullptr, nullptr}
 const MidLauncher g_mid[3][2][3][3] = {
     {{GS_MID_ROW(0, 0, 512, 16), GS_MID_ROW(4, 0, 512, 16), GS_MID_ROW(8, 0, 512, 16)},
      {GS_MID_ROW(0, 1, 512, 16), GS_MID_ROW(4, 1, 512, 16), GS_MID_ROW(8, 1, 512, 16)}},
     {{GS_MID_ROW(0, 0, 512, 32), GS_MID_ROW(4, 0, 512, 32), GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32), GS_MID_ROW(4, 1, 512, 32), GS_MID_NONE}},
-    {{GS_MID_ROW(0, 0, 1024, 32), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 1024, 32), GS_MID_NONE, GS_MID_NONE}},
+    {{GS_MID_ROW(0, 0, 512, 32, 1024, 32), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32, 1024, 32), GS_MID_NONE, GS_MID_NONE}},
 };
 #endif
-constexpr uint32_t g_mid_tile[3] = {512 * 16, 512 * 32, 1024 * 32};
-// tile class of a mid-size sort, -1: the general pipeline
+constexpr uint32_t g_mid_tile[3] = {512 * 16, 512 * 32, 512 * 32};  // K1's tile
+constexpr uint32_t g_mid_tiles[3] = {128, 128, 256};                 // ... and how many of them at most (<= MID_MAX_TILES)
+static_assert(g_mid_tiles[2] <= gs::MID_MAX_TILES, "mid-size classes");
+// class of a mid-size sort, -1: the general pipeline
 inline int mid_class(uint32_t n, uint32_t vb) {
-    if (n <= gs::MID_MAX_TILES * g_mid_tile[0]) return 0;
-    if (n <= gs::MID_MAX_TILES * g_mid_tile[1] && vb != 8) return 1;
-    if (n <= gs::MID_MAX_TILES * g_mid_tile[2] && vb == 0) return 2;
+    if (n <= g_mid_tiles[0] * g_mid_tile[0]) return 0;
+    if (n <= g_mid_tiles[1] * g_mid_tile[1] && vb != 8) return 1;
+    if (n <= g_mid_tiles[2] * g_mid_tile[2] && vb == 0) return 2;
     return -1;
 }
 

@@ -41,8 +41,8 @@ namespace gs {
 //   512 x 32 = 16 384 keys  n <= 2^21   keys-only and 4-byte values (stage 64 + 64 KiB)
 //  1024 x 32 = 32 768 keys  n <= 2^22   keys-only (stage 128 KiB)
 constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // the smallest shape
-constexpr uint32_t MID_MAX_TILES = 128;
-constexpr uint32_t MID_MAX_KEYS = MID_MAX_TILES * MID_TILE;                            // 2^20: limit of the smallest shape
+constexpr uint32_t MID_MAX_TILES = 256;                                                // (the smallest shape stops at 128: one launch wave of half the CUs)
+constexpr uint32_t MID_MAX_KEYS = 128 * MID_TILE;                                      // 2^20: limit of the smallest shape
 // scratch words in the handle's slab (SLAB_MID)
 constexpr uint32_t MID_EPOCH = 0;                   // epoch of the call whose plan (route, bucket table) is below — K2's licence
 constexpr uint32_t MID_CTR = 8;                     // epoch of the last completed call (advanced by K2's last workgroup)
@@ -51,10 +51,10 @@ constexpr uint32_t MID_RESET = 16;                  // epoch of the call whose f
 constexpr uint32_t MID_ROUTE = 32;                  // 0 = MSD route (K2 sorts the buckets), 1 = K1 did the LSD passes
 constexpr uint32_t MID_BSTART = 64;                 // bucket starts [256]
 constexpr uint32_t MID_BCOUNT = MID_BSTART + RADIX; // bucket counts [256]
-constexpr uint32_t MID_CLAIM = MID_BCOUNT + RADIX;  // [128] epoch of the call in which the tile was claimed
-constexpr uint32_t MID_AFLAG = MID_CLAIM + MID_MAX_TILES;  // [128] tag of the tile's last published count row
-constexpr uint32_t MID_BFLAG = MID_AFLAG + MID_MAX_TILES;  // [128] tag of the tile's last finished scatter (LSD route)
-constexpr uint32_t MID_TABLE = 1024;                // two count tables [2][MID_MAX_TILES][256]
+constexpr uint32_t MID_CLAIM = MID_BCOUNT + RADIX;  // [MID_MAX_TILES] epoch of the call in which the tile was claimed
+constexpr uint32_t MID_AFLAG = MID_CLAIM + MID_MAX_TILES;  // [..] tag of the tile's last published count row
+constexpr uint32_t MID_BFLAG = MID_AFLAG + MID_MAX_TILES;  // [..] tag of the tile's last finished scatter (LSD route)
+constexpr uint32_t MID_TABLE = 2048;                // two count tables [2][MID_MAX_TILES][256]
 constexpr uint32_t MID_WORDS = MID_TABLE + 2 * MID_MAX_TILES * RADIX;
 static_assert(MID_BFLAG + MID_MAX_TILES <= MID_TABLE, "mid scratch layout");
 static_assert(MID_WORDS <= SLAB_MID_WORDS, "SLAB_MID is too small");
@@ -79,6 +79,7 @@ __device__ __forceinline__ void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_s
 __device__ __forceinline__ void st_sc1(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+typedef uint32_t tv4 __attribute__((ext_vector_type(4)));
 template <int VB>
 struct SC1T { using type = uint32_t; };
 template <>
@@ -87,14 +88,16 @@ struct SC1T<8> { using type = unsigned long long; };
 // Rank the tile's keys among the keys of their digit inside their wave (see digit_binning_kernel): off = the ranks (below
 // 64 * KPT <= 2048: two per register, which keeps the 32-keys-per-thread shapes out of scratch), the per-wave counters keep the counts.  RANK 1: slots >= count take no part; RANK 0 (ballots): the all-ones dummy
 // keys behind `count` rank last in digit 255.
+// kpt_eff (uniform, <= KPT): slots per thread in use — K2 spreads a bucket that fills only part of the tile over ALL waves.
 template <int RANK, int KPT>
 __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t shift, uint32_t my_base, uint32_t count,
-                                         uint32_t* whist, uint32_t (&off)[KPT / 2]) {
+                                         uint32_t* whist, uint32_t (&off)[KPT / 2], uint32_t kpt_eff = KPT) {
 #pragma unroll
     for (int i = 0; i < KPT / 2; ++i) off[i] = 0;
     if constexpr (RANK == 0) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt_eff) continue;  // uniform
             const uint32_t d = (key[i] >> shift) & 255u;
             uint32_t acc_lo = 0, acc_hi = 0;
 #pragma unroll
@@ -115,6 +118,7 @@ __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t sh
     } else {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt_eff) continue;  // uniform
             const uint32_t d = (key[i] >> shift) & 255u;
             if (my_base + i * 64u < count)
                 off[i >> 1] |= __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << (16 * (i & 1));
@@ -125,7 +129,8 @@ __device__ __forceinline__ void mid_rank(const uint32_t (&key)[KPT], uint32_t sh
 // ---------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------
-template <int VB, int KT, int RANK, int THREADS_ = (int)MID_THREADS, int KPT_ = (int)MID_KPT>
+// BUCKET_CAP: keys K2's workgroup can hold (its tile) — a larger bucket sends the sort down the LSD route
+template <int VB, int KT, int RANK, int THREADS_ = (int)MID_THREADS, int KPT_ = (int)MID_KPT, int BUCKET_CAP = THREADS_ * KPT_>
 __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint32_t* alt, void* vals_, void* valt_, uint32_t* scratch,
                                                            uint32_t* status, uint32_t n, uint32_t descending) {
     using V = typename ValT<VB>::type;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
     __shared__ __attribute__((aligned(16))) V s_vstage[VB != 0 ? TILE : 1];
     __shared__ uint32_t s_whist[WAVES * RADIX];
-    __shared__ uint32_t s_dpre[RADIX], s_gbase[RADIX], s_wtot[4], s_max;
+    __shared__ uint32_t s_dpre[RADIX], s_gbase[RADIX], s_gsum[RADIX], s_front[RADIX], s_wtot[4], s_max;
     __shared__ uint32_t s_owned[MID_MAX_TILES];  // tiles this workgroup has claimed: its own first, then the adopted ones
     __shared__ uint32_t s_ctl[4];                // [0] claim result / adopt result, [1] first tile whose flag is missing, [2] failed
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -262,6 +267,36 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     // global bases of the tile in the registers from the complete table: leaves s_gbase[d] = global position of stage slot 0
     // of digit d's run minus its stage offset, s_whist[w][d] += run offset, and returns G (all tiles' count of the digit)
     auto bases = [&](uint32_t* table) -> uint32_t {
+        // every tile's count of every digit: all of them for the digit's start, the tiles in front for this tile's offset.
+        // The whole workgroup reads the table: lane l of wave w takes digits 4 l .. 4 l + 3 of rows w, w + WAVES, .. with
+        // 16-byte sc1 loads, NB in flight (one thread per digit walking the rows eight at a time took tiles / 8 round
+        // trips of ~1 us: 16 of the 44 us of this kernel at 2^22 keys, profiles/r03_mid_size_timeline.txt); rows behind
+        // the table's end read as zero (buffer range check).
+        if (tid < RADIX) { s_gsum[tid] = 0u; s_front[tid] = 0u; }
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(table, 0, (int)(tiles * RADIX * 4u), 0x00020000);
+            uint32_t g4[4] = {0u, 0u, 0u, 0u}, f4[4] = {0u, 0u, 0u, 0u};
+            constexpr uint32_t NB = (VB != 0 && KPT >= 32) ? 2u : 8u;  // loads in flight (the 32-pairs-per-thread shape has no registers to spare: 4 spill 100 B per lane)
+            for (uint32_t t0 = wave; t0 < tiles; t0 += NB * WAVES) {  // (uniform bounds)
+                tv4 c[NB];
+#pragma unroll
+                for (uint32_t j = 0; j < NB; ++j)
+                    c[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((t0 + j * WAVES) * RADIX + lane * 4u) * 4u), 0, 16 /*sc1*/);
+#pragma unroll
+                for (uint32_t j = 0; j < NB; ++j) {
+                    const bool in_front = t0 + j * WAVES < cur_tile;  // uniform
+                    g4[0] += c[j].x; g4[1] += c[j].y; g4[2] += c[j].z; g4[3] += c[j].w;
+                    if (in_front) { f4[0] += c[j].x; f4[1] += c[j].y; f4[2] += c[j].z; f4[3] += c[j].w; }
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (g4[k]) atomicAdd(&s_gsum[lane * 4u + k], g4[k]);
+                if (f4[k]) atomicAdd(&s_front[lane * 4u + k], f4[k]);
+            }
+        }
+        __syncthreads();
         uint32_t G = 0;
         if (tid < RADIX) {
             uint32_t wbase = 0;
@@ -270,25 +305,10 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
             s_dpre[tid] = dpre;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
-            // every tile's count of this digit: all of them for the digit's start, the tiles in front for this tile's offset
-            uint32_t front = 0;
-            for (uint32_t t0 = 0; t0 < tiles; t0 += 8) {
-                uint32_t c[8];
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    const uint32_t t = t0 + j < tiles ? t0 + j : tiles - 1u;
-                    c[j] = ld_sc1(&table[t * RADIX + tid]);
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j)
-                    if (t0 + j < tiles) {
-                        G += c[j];
-                        if (t0 + j < cur_tile) front += c[j];
-                    }
-            }
+            G = s_gsum[tid];
             atomicMax(&s_max, G);
             scan_incl = wave_inclusive_scan_dpp(G);
-            s_gbase[tid] = front - dpre;  // + digit start, below
+            s_gbase[tid] = s_front[tid] - dpre;  // + digit start, below
         }
         __syncthreads();
         if (tid < RADIX && lane == 63) s_wtot[wave] = scan_incl;
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
         rank_and_publish(24, table0, 0u, false);
     }
     const uint32_t G = bases(table0);
-    const bool lsd_route = uni(s_max) > TILE;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
+    const bool lsd_route = uni(s_max) > (uint32_t)BUCKET_CAP;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
     __syncthreads();                      // everybody has read s_max before the next ranking resets it
     // K2's plan, written by whoever owns tile 0 (its own workgroup, or the one that adopted it) while that tile is at hand
     auto write_plan = [&]() {  // the registers / LDS hold tile 0
@@ -431,26 +451,32 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
     const uint32_t start = scratch[MID_BSTART + blockIdx.x], count = scratch[MID_BCOUNT + blockIdx.x];
     if (count == 0u || count > TILE || start > n || count > n - start) work = false;  // (the last three cannot happen with a valid plan)
     if (work) {
-    const uint32_t my_base = wave * (64u * KPT) + lane;
+    // A bucket rarely fills the tile (n / 256 keys on average, the tile holds the class's worst case): its keys are spread
+    // over ALL waves, kpt slots per thread, instead of filling the first waves with KPT each — the ranking phases take
+    // as long as the busiest wave.  Slot order = wave-major, then i, then lane, as before: stable.
+    const uint32_t kpt = (uint32_t)__builtin_amdgcn_readfirstlane((int)((count + THREADS - 1u) / THREADS));  // uniform, 1 .. KPT
+    const uint32_t my_base = wave * (64u * kpt) + lane;
     uint32_t* whist = s_whist + wave * RADIX;
     uint32_t key[KPT];
     V val[VB != 0 ? KPT : 1];
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;  // uniform
         const uint32_t slot = my_base + i * 64u;
         const uint32_t ci = start + (slot < count ? slot : count - 1u);
         key[i] = alt[ci];
         if constexpr (VB != 0) val[i] = reinterpret_cast<const V*>(valt_)[ci];
     }
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
+    for (int i = 0; i < KPT; ++i)
+        if ((uint32_t)i < kpt) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
     // a bucket of 64 keys or fewer could stop earlier; the three passes on LDS cost a few microseconds at any size
 #pragma unroll 1
     for (uint32_t shift = 0; shift < 24; shift += 8) {
         for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
         __syncthreads();
         uint32_t off[KPT / 2];
-        mid_rank<RANK, KPT>(key, shift, my_base, count, whist, off);
+        mid_rank<RANK, KPT>(key, shift, my_base, count, whist, off, kpt);
         __syncthreads();
         uint32_t run = 0, scan_incl = 0;
         if (tid < RADIX) {
@@ -474,6 +500,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
             const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
             if (RANK == 0 || my_base + i * 64u < count) {
                 s_stage[lpos] = key[i];
@@ -483,6 +510,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
             key[i] = s_stage[my_base + i * 64u];
             if constexpr (VB != 0) val[i] = s_vstage[my_base + i * 64u];
         }
@@ -490,7 +518,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t slot = my_base + i * 64u;
-        if (slot < count) {
+        if ((uint32_t)i < kpt && slot < count) {
             const uint32_t idx = start + slot;
             const uint32_t o = descending ? n - 1u - idx : idx;
             keys[o] = from_bits<KT>(key[i]);

@@ -67,6 +67,19 @@
 #define GS_ABL_CLOCKS_END() do { if (((GS_EXP)&1024) && blockIdx.x == 0 && threadIdx.x == 0) { \
         unsigned long long* c_ = reinterpret_cast<unsigned long long*>(slab + SLAB_STATUS + 16); \
         c_[0] = abl_c0_; c_[1] = abl_w0_; c_[2] = (unsigned long long)clock64(); c_[3] = (unsigned long long)wall_clock64(); } } while (0)
+// 4096: phase stamps of the histogram kernel (10 ns ticks of the 100 MHz counter, low words): the first and the last workgroup
+//       write eight each into the slab at STATUS+16 / STATUS+24 — tools/r03_hist_phases.py (build with 1024 too: the reader)
+#if (GS_EXP & 4096)
+#define GS_HIST_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) abl_stamp_[(i)] = (uint32_t)wall_clock64(); } while (0)
+#define GS_HIST_STAMPS_DECL() uint32_t abl_stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GS_HIST_STAMPS_OUT() do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); abl_stamp_[7] = (uint32_t)wall_clock64(); \
+        for (int i_ = 0; i_ < 8; ++i_) slab[SLAB_STATUS + (blockIdx.x == 0 ? 16 : 24) + i_] = abl_stamp_[i_]; } } while (0)
+#else
+#define GS_HIST_STAMP(i) do { } while (0)
+#define GS_HIST_STAMPS_DECL() do { } while (0)
+#define GS_HIST_STAMPS_OUT() do { } while (0)
+#endif
 #if (GS_EXP & 256)
 #define GS_ABL_ASSUME_PREV() do { if (!finished) { prev = (ld_agent(&cdesc[tid]) >> 2) + tile * tile_total; done = true; } } while (0)
 #else

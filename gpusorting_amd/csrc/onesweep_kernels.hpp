@@ -82,6 +82,9 @@ static_assert(NCH >= 1 && NCH <= 32 && (NCH & (NCH - 1)) == 0, "GS_NCHAINS must 
 #define GS_ABL_EARLY_USE(v) do { } while (0)   // ... and take it in the look-back if it is INCLUSIVE
 #define GS_ABL_CLOCKS_BEGIN() do { } while (0)  // histogram kernel: shader clock against the 100 MHz wall clock
 #define GS_ABL_CLOCKS_END() do { } while (0)
+#define GS_HIST_STAMP(i) do { } while (0)       // histogram kernel: phase time stamps of its first and last workgroup
+#define GS_HIST_STAMPS_DECL() do { } while (0)
+#define GS_HIST_STAMPS_OUT() do { } while (0)
 #define GS_ABL_COUNT_LDS 0                     // extra LDS of the next-digit counting experiment
 #define GS_ABL_COUNT_NEXT(kb, o) do { } while (0)
 #endif
@@ -158,7 +161,7 @@ constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): plan epoch, route flag, bucket table, per-tile
 // claim / flag words, two count tables of MID_MAX_TILES rows
 constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
-constexpr uint32_t SLAB_MID_WORDS = 1024 + 2 * 128 * RADIX;
+constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
 constexpr uint32_t SLAB_DESC = SLAB_MID + SLAB_MID_WORDS;
 static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
@@ -350,11 +353,13 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     // 256 bins collide on ADDRESSES, which serialises atomics), and a constant low byte — every lane on one
     // counter, 128 clk — costs nothing here.  Folded into s_h when the workgroup's segment changes, every
     // HIST_FOLD_CHUNKS chunks (a replica sees 128 keys per chunk: 16-bit counters hold 511 chunks), and at the end.
-    __shared__ uint32_t s_r[RADIX / 2 * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_r[RADIX / 2 * 32];
 #endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t* hist = slab + SLAB_HIST;
     GS_ABL_CLOCKS_BEGIN();
+    GS_HIST_STAMPS_DECL();
+    GS_HIST_STAMP(0);
     // This kernel is also the sort's CLEAR (reference: ClearMemory, OneSweepDispatcher.cuh:301-309): it zeroes the
     // scan state nobody reads before it ends — ticket counters, status, info, slice counts, descriptors — as
     // 16-byte grid-stride stores next to its read stream; a separate memset was one more launch (5 us of a 50 us
@@ -375,22 +380,34 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #if GS_HIST_REPLICAS
     for (uint32_t i = tid; i < RADIX / 2 * 32; i += GHIST_THREADS) s_r[i] = 0;
     uint32_t cur_x0 = 0xffffffffu, since_fold = 0;  // uniform: segment the replicas are counting for, chunks since the last fold
+    // Eight threads share the 32 replicas of a counter pair (one 16-byte read each, conflict-free), sum them with three
+    // butterfly steps, and the first of them owns the two bins they go to.  (One LDS add per non-empty replica word had the
+    // 32 replicas of a pair meet on ONE address: 128 wave-adds of 32 serial steps each, 9 us per fold — half of this
+    // kernel's fixed cost at mid sizes and 3 % of it at 2^28, profiles/r03_hist_phases.txt.)
     auto fold = [&](uint32_t x) {
         __syncthreads();
-        if (x != 0xffffffffu)
-            for (uint32_t i = tid; i < RADIX / 2 * 32; i += GHIST_THREADS) {
-                const uint32_t v = s_r[i];
-                if (v) {
-                    s_r[i] = 0;
-                    const uint32_t d = (i >> 5) << 1;
-                    if (v & 0xffffu) atomicAdd(&s_h[hist_index(0, d, x)], v & 0xffffu);
-                    if (v >> 16) atomicAdd(&s_h[hist_index(0, d + 1u, x)], v >> 16);
+        if (x != 0xffffffffu) {
+            for (uint32_t i = tid; i < RADIX / 2 * 8; i += GHIST_THREADS) {  // (one round with 1024 threads)
+                const uint4 v = reinterpret_cast<const uint4*>(s_r)[i];
+                reinterpret_cast<uint4*>(s_r)[i] = uint4{0u, 0u, 0u, 0u};
+                uint32_t lo = (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+                uint32_t hi = (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                    lo += __shfl_xor(lo, m, 64);
+                    hi += __shfl_xor(hi, m, 64);
+                }
+                if ((i & 7u) == 0u) {
+                    s_h[hist_index(0, (i >> 3) * 2u, x)] += lo;
+                    s_h[hist_index(0, (i >> 3) * 2u + 1u, x)] += hi;
                 }
             }
+        }
         __syncthreads();
     };
 #endif
     __syncthreads();
+    GS_HIST_STAMP(1);
 
     const uint32_t shift0 = p0 * 8u;
     auto bin_of = [&](uint32_t b, uint32_t q, uint32_t x0) -> uint32_t {
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
 #pragma unroll
                 for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<0>{}, t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
             }
+            if (c0 == c_first) GS_HIST_STAMP(2);
             if (allow_pos && c0 == c_first && !joint_off) {
                 // Are the digit groups even?  The chains of passes 1..3 are the NCH groups of the previous digit's values:
                 // with skewed keys (Thearling-Smith presets 2..5: group 0 holds 32 .. 88 % of them) one chain gets most
@@ -532,6 +550,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                 }
                 __syncthreads();
                 joint_off = joint_off || s_uneven != 0u;
+                GS_HIST_STAMP(3);
             }
             continue;
         }
@@ -559,11 +578,13 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             }
         }
     }
+    GS_HIST_STAMP(4);
 #if GS_HIST_REPLICAS
     fold(cur_x0);
 #else
     __syncthreads();
 #endif
+    GS_HIST_STAMP(5);
     // The workgroup's tables go out as they are — coalesced plain stores into its own slice — and hist_reduce_kernel sums the
     // slices.  (One global atomic per non-empty bin cost 256 workgroups x ~14 000 device-scope atomics on the same 16 384 words:
     // 20-40 us of every sort from 2^23 keys up, half of this kernel at 2^23, profiles/r03_mid_size_routes.txt.)
@@ -574,13 +595,17 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     }
     // (measured: accumulating the OR / AND of all keys here, to drop constant bytes in position-chain sorts too, cost 0.08 ms)
     if (tid == 0 && joint_off) atomicOr(&hist[HIST_TABLE_WORDS + HX_SKEW], 1u);
+    GS_HIST_STAMP(6);
     GS_ABL_CLOCKS_END();
+    GS_HIST_STAMPS_OUT();
 }
 
 // Sum of the histogram workgroups' tables: hist[i] = sum over workgroups of partials[w][i].  A workgroup of 256 threads owns
 // 64 consecutive bins; thread (g, b) = (tid / 64, tid % 64) sums every fourth slice of bin b — 256-byte wave loads, up to
 // 8 in flight, at most nblocks / 4 of them in a row — and the four partial sums meet in LDS.  (One thread per bin, 256 loads
 // in a row, was latency-bound: 30 us.)  The HIST region is overwritten, not accumulated into.
+// (Measured and not kept: the Scan run by the LAST workgroup of this kernel to store its sums — sc1 stores, a ticket, the four
+//  passes one after the other on one CU — 22 us instead of 5 + 5 for the two kernels, profiles/r03_mid_size_timeline.txt.)
 __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t* __restrict__ partials, uint32_t nblocks, uint32_t bins,
                                                            uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_part[4][64];
@@ -1307,6 +1332,8 @@ __device__ __forceinline__ void binning_body(
     GS_ABL_EARLY_USE(early_row);
     for (;;) {
         if (!finished) {
+            // (measured in round 3 and not kept: four rows per trip in short sorts — 2^20 .. 2^25 keys, where the tiles of a chain
+            //  run in step and the walks are ~5 trips: no change, the wait is for the predecessor, profiles/r03_mid_size_timeline.txt)
             walk(IntTag<GS_WALK_ROWS>{});
             if (done) {
                 finished = true;

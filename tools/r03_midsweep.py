@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 3: keys-only sorts of 2^21 .. 2^27 keys, back-to-back (20 per point), under the environment's routing.
-Usage: [GPUSORT_POS=2 GPUSORT_POS_MIN_LOG2=22] python tools/r03_midsweep.py [vb=0]"""
+Usage: [GPUSORT_POS=2 GPUSORT_POS_MIN_LOG2=22] python tools/r03_midsweep.py [vb=0] [log2 from=21] [log2 to=27]"""
 import os
 import sys
 
@@ -11,7 +11,9 @@ import gpusorting_amd as g  # noqa: E402
 
 vb = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 row = []
-for lg in range(21, 28):
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 21
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else 27
+for lg in range(lo, hi + 1):
     n = 1 << lg
     nb = max(2, min(20, (1 << 30) // (n * 4)))
     ks = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(nb)]

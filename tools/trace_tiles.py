@@ -47,6 +47,9 @@ def main():
               ts[:, 6] - ts[:, 5], ts[:, 6] - ts[:, 0]]
         trips = x[:, 7] & 0xffff
         print(f"pass {p}: tiles {len(x)} span {span:.1f} us; look-back trips mean {trips.mean():.2f} p99 {np.percentile(trips,99):.0f} max {trips.max()}")
+        st = (ts[:, 0] - ts[:, 0].min()) / 100.0
+        en = (ts[:, 6] - ts[:, 0].min()) / 100.0
+        print(f"    tile start after the first: p50 {np.median(st):.2f} p90 {np.percentile(st,90):.2f} max {st.max():.2f} us;  tile end: p10 {np.percentile(en,10):.2f} p50 {np.median(en):.2f} max {en.max():.2f} us")
         for nm, v in zip(names, ph):
             v = v / 100.0
             print(f"    {nm:16s} mean {v.mean():6.2f}  p50 {np.median(v):6.2f}  p90 {np.percentile(v,90):6.2f}  p99 {np.percentile(v,99):6.2f}  max {v.max():7.2f} us")
