@@ -148,6 +148,7 @@ using gs::SLAB_INFO;
 using gs::SLAB_STATUS;
 
 constexpr uint32_t MIN_TILE = 4096;  // smallest tile of any compiled shape (sizing of the slab)
+constexpr uint32_t KEY64_TILE = 8192;  // tile of every sort of 64-bit keys (MID_SHAPE: 8-byte stage slots, 64 KiB)
 constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb) unless the caller picked a shape
 // profiles/r02_shape_by_size.txt (general path, back-to-back sorts): the 8192-key tile wins up to 2^25 keys for keys-only
 // sorts (180 vs 194 us at 2^24, 293 vs 302 at 2^25, loses at 2^26) and for 8-byte values (whose big tile leaves one
@@ -166,6 +167,7 @@ struct gs_onesweep {
     int mid_path;    // 1 = two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (default), 0 = the six-launch path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int pos_chains;  // keys-only sorts of skewed 32-bit keys run every pass on position chains: 1 allowed (default), 0 never
+    int key64_sweeps;       // 64-bit keys: 1 = one GlobalHistogram + Scan for all eight passes (default), 2 = one per word (GPUSORT_KEY64_SWEEPS; A/B, tests)
     uint32_t pos_min_keys;  // ... from this many keys up (default 2^25 + 1: where the big tile shape takes over; GPUSORT_POS_MIN_LOG2)
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
@@ -189,8 +191,10 @@ struct gs_onesweep {
 namespace {
 
 size_t slab_words_for(uint32_t max_keys) {
-    const size_t max_tiles = div_up(max_keys, MIN_TILE);
-    return SLAB_DESC + 4 * (max_tiles + 2 * gs::MAXCH + 2) * (size_t)gs::RADIX;
+    // descriptor rows: four passes on the smallest tile, or the eight passes of a 64-bit sort on its 8192-key tile
+    const size_t rows4 = 4 * ((size_t)div_up(max_keys, MIN_TILE) + 2 * gs::MAXCH + 2);
+    const size_t rows8 = gs::MAX_PASSES * ((size_t)div_up(max_keys, KEY64_TILE) + 2 * gs::MAXCH + 2);
+    return SLAB_DESC + (rows4 > rows8 ? rows4 : rows8) * (size_t)gs::RADIX;
 }
 
 using HistLauncher = void (*)(hipStream_t, uint32_t, const uint32_t*, uint32_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
@@ -266,6 +270,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const uint32_t rows = ((scan_plan & 4u) && POS_TILE < tile ? div_up(n, POS_TILE) : tiles) + 2 * gs::MAXCH + 2;
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
+    if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
     // position segments of the first pass: equal, multiples of the histogram chunk
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
     // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
@@ -273,7 +278,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
     // between left it dirty: zero it here, once, instead of double counting silently.
     if (h->hist_dirty) GS_HIP(zero_hist(h, s));
-    // (64-bit keys: the second round's kernels are charged to slot 6 — its events stay where round 0 put them)
+    // (64-bit keys: passes 4..7 — or the second round's kernels — are charged to slot 6; the events of round 0 stay where they are)
     const bool rec = h->profiling && word == 0;
     if (rec) GS_HIP(hipEventRecord(h->ev[0], s));
     if (rec) GS_HIP(hipEventRecord(h->ev[1], s));
@@ -284,8 +289,12 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
     if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL(gs::scan_kernel, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                       h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
+    if (np > 4)  // 64-bit keys: all eight passes from one sweep
+        hipLaunchKernelGGL(gs::scan_kernel<8>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
+    else
+        hipLaunchKernelGGL(gs::scan_kernel<4>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
     if (rec) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->desc_stride = desc_stride;
@@ -429,10 +438,15 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                      (vb == 0 ? g_dual : g_pos8)[0][kt] != nullptr && sh.threads == 512 && sh.kpt == 32;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
-    // 64-bit keys: two rounds of histogram + scan + 4 passes — the low word's bytes, then (stable) the high word's.
-    // Each round leaves its result in the caller's buffers (an even number of passes runs, or identity passes are
-    // dropped in pairs), and only the last round carries the descending reversal.
-    const uint32_t rounds = is_key64(kt) ? 2u : 1u;
+    // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
+    // chains of pass 4 are the groups of byte 3's values, as inside a word) — identity passes are dropped in pairs across the
+    // whole key (keys below 2^32: four passes).  GPUSORT_KEY64_SWEEPS=2 (A/B) or a caller-picked tile too small for the slab's
+    // eight descriptor regions: two rounds of histogram + scan + 4 passes — the low word's bytes, then (stable) the high
+    // word's; each round leaves its result in the caller's buffers, only the last one carries the descending reversal.
+    const bool one_sweep = is_key64(kt) && h->key64_sweeps == 1 &&
+                           SLAB_DESC + (size_t)gs::MAX_PASSES * (div_up(n, (uint32_t)sh.threads * sh.kpt) + 2 * gs::MAXCH + 2) * gs::RADIX <= h->slab_words;
+    const uint32_t rounds = (is_key64(kt) && !one_sweep) ? 2u : 1u;
+    const uint32_t NP = one_sweep ? gs::MAX_PASSES : 4u;
 #if (GS_EXP & (1024 | 2048))
     const uint32_t exp_mode = getenv("GPUSORT_EXPMODE") ? (uint32_t)atoi(getenv("GPUSORT_EXPMODE")) & (256u | 512u | 1024u | 2048u) : 0u;
     h->exp_keep_desc = (exp_mode & 256u) != 0u;
@@ -442,12 +456,12 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word);
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word);
         if (st != GS_OK) return st;
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
-        for (uint32_t p = 0; p < 4; ++p) {
+        for (uint32_t p = 0; p < NP; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
-            const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == 3) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
+            const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == NP - 1) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
             // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
             const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
             if (pos && vb == 0)  // one launch serves both plans (persistent workgroups, two per CU)
@@ -469,10 +483,10 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
                                    (mode & ~4u) | 64u);
-            if (h->profiling && word == 0) GS_HIP(hipEventRecord(h->ev[4 + p], s));
+            if (h->profiling && word == 0 && p < 4) GS_HIP(hipEventRecord(h->ev[4 + p], s));
         }
     }
-    if (h->profiling && rounds == 2) GS_HIP(hipEventRecord(h->ev[7], s));  // slot 6 then holds pass 3 of round 0 + all of round 1
+    if (h->profiling && is_key64(kt)) GS_HIP(hipEventRecord(h->ev[7], s));  // slot 6 then holds pass 3 and everything behind it
     GS_HIP(hipGetLastError());
     h->hist_dirty = false;  // pass 0 (mode bit 2) was launched: it zeroes HIST
     h->profile_pending = h->profiling != 0;
@@ -562,6 +576,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     }
     if (const char* env = getenv("GPUSORT_POS")) h->pos_chains = atoi(env);  // 0 never, 1 when the keys are skewed, 2 always (tests, tuning)
     if (h->pos_chains < 0 || h->pos_chains > 2) h->pos_chains = 1;
+    h->key64_sweeps = (getenv("GPUSORT_KEY64_SWEEPS") && atoi(getenv("GPUSORT_KEY64_SWEEPS")) == 2) ? 2 : 1;
     h->skip_passes = 1;
     if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
     h->mid_path = 1;

@@ -149,11 +149,12 @@ constexpr uint32_t SLAB_COUNTERS = 0;
 constexpr uint32_t COUNTER_STRIDE = 32;  // one 128-byte line per ticket counter: chains do not share a line
 constexpr uint32_t COUNTERS_PER_PASS = 72;  // >= MAXCH
 static_assert(COUNTERS_PER_PASS >= MAXCH, "ticket counters");
-constexpr uint32_t SLAB_STATUS = 4 * COUNTERS_PER_PASS * COUNTER_STRIDE;
+constexpr uint32_t MAX_PASSES = 8;  // 64-bit keys: one GlobalHistogram + Scan plans all eight passes (32-bit keys use the first four slots)
+constexpr uint32_t SLAB_STATUS = MAX_PASSES * COUNTERS_PER_PASS * COUNTER_STRIDE;
 constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
-constexpr uint32_t SLAB_HIST = SLAB_INFO + 4 * INFO_STRIDE + 32;
-// behind the four joint tables: what else the histogram kernel tells the Scan kernel (zero between calls, like the tables)
-constexpr uint32_t HIST_TABLE_WORDS = 4 * NCH * RADIX;
+constexpr uint32_t SLAB_HIST = SLAB_INFO + MAX_PASSES * INFO_STRIDE + 32;
+// behind the joint tables: what else the histogram kernel tells the Scan kernel (zero between calls, like the tables)
+constexpr uint32_t HIST_TABLE_WORDS = MAX_PASSES * NCH * RADIX;
 constexpr uint32_t HX_SKEW = 0;  // a workgroup found the digit groups of its keys uneven and stopped counting the joint tables
 constexpr uint32_t HIST_WORDS = HIST_TABLE_WORDS + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
@@ -193,9 +194,10 @@ constexpr uint32_t HIST_FOLD_CHUNKS = 256;  // replicas are folded at least this
 constexpr uint32_t HIST_CHUNK = 4 * GS_GHIST_THREADS;  // keys per histogram work item (4 per thread); position segments are multiples of it
 
 enum : int { KEY_U32 = 0, KEY_I32 = 1, KEY_F32 = 2, KEY_U64 = 3, KEY_I64 = 4, KEY_F64 = 5 };
-// 64-bit keys (8 passes; the reference has 32-bit keys only) are sorted as two 4-pass rounds over
-// the SAME machinery: round 0 partitions by the bytes of the low word, round 1 (stable) by the bytes of the high
-// word; both words travel as one 8-byte element.  KW = 32-bit words per key.
+// 64-bit keys (8 passes; the reference has 32-bit keys only) are sorted by eight passes of the SAME
+// machinery — the digit of pass p is byte p & 3 of word p >> 2, both words travel as one 8-byte element — planned by one
+// GlobalHistogram sweep (eight joint tables) and one Scan (MAX_PASSES info blocks, ticket rows and descriptor regions).
+// KW = 32-bit words per key.
 template <int KT>
 struct KeyWords { static constexpr int value = KT >= KEY_U64 ? 2 : 1; };
 
@@ -330,8 +332,11 @@ __host__ __device__ constexpr uint32_t hist_index(uint32_t q, uint32_t d, uint32
     return q == 0 ? x * RADIX + d : (q * RADIX + d) * NCH + x;
 }
 
-// 64-bit keys: `word` selects the 32-bit word the np digits are taken from (the sort's round); a work item is still
-// HIST_CHUNK keys — two 16-byte loads per thread instead of one.
+// 64-bit keys: np <= 4: `word` selects the 32-bit word the np digits are taken from (stand-alone passes, the multi-GPU split);
+// np == 8 (the sort): ONE sweep counts all eight tables — the digits of the low word as above, byte 4's table joint with the
+// low word's top bits (the bin is the 12-bit field at bit 28 of the 64-bit key), bytes 5..7 inside the high word — so
+// the sort reads its keys once for the histogram instead of once per word (8 x 4096 bins: 128 KiB of LDS).  A work item is
+// still HIST_CHUNK keys — two 16-byte loads per thread instead of one.
 template <int KT>
 __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                          uint32_t* slab, size_t slab_used_words,
@@ -343,7 +348,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                                                                          uint32_t* partials /*[gridDim][HIST_TABLE_WORDS]: every
                                                                          workgroup's tables, summed by hist_reduce_kernel*/) {
     constexpr int KW = KeyWords<KT>::value;
-    __shared__ uint32_t s_h[4 * NCH * RADIX];
+    constexpr uint32_t NQ = KW == 2 ? MAX_PASSES : 4;  // tables a workgroup can count
+    __shared__ uint32_t s_h[NQ * NCH * RADIX];
     __shared__ uint32_t s_uneven;  // a digit group of this workgroup's first work item holds more than GS_POS_SHARE of its keys
 #if GS_HIST_REPLICAS
     // Pass-0 digit counts on 32 lane-private replicas, 16-bit counters packed two per dword: dword (d >> 1) * 32 +
@@ -410,21 +416,29 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     GS_HIST_STAMP(1);
 
     const uint32_t shift0 = p0 * 8u;
-    auto bin_of = [&](uint32_t b, uint32_t q, uint32_t x0) -> uint32_t {
+    const bool both = KW == 2 && np > 4u;  // uniform: all eight tables of a 64-bit key in this sweep (p0 = 0)
+    // b: the word the first four digits come from, hi: the key's high word (both only)
+    auto bin_of = [&](uint32_t b, uint32_t hi, uint32_t q, uint32_t x0) -> uint32_t {
         if (q == 0) return hist_index(0, (b >> shift0) & 255u, x0);
-        return q * (RADIX * NCH) + __builtin_amdgcn_ubfe(b, shift0 + 8u * q - LOG_NCH, 8u + LOG_NCH);
+        if (q < 4) return q * (RADIX * NCH) + __builtin_amdgcn_ubfe(b, shift0 + 8u * q - LOG_NCH, 8u + LOG_NCH);
+        if (q == 4) return 4u * (RADIX * NCH) + (((hi & 255u) << LOG_NCH) | (b >> (32u - LOG_NCH)));
+        return q * (RADIX * NCH) + __builtin_amdgcn_ubfe(hi, 8u * (q - 4u) - LOG_NCH, 8u + LOG_NCH);
     };
 
     uint32_t skew_mode = 0;  // bit q (wave-uniform): a dominant bin was seen for byte q; cleared when it fades
-    uint32_t sticky[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // wave-uniform guess of that bin
+    uint32_t sticky[NQ];     // wave-uniform guess of that bin
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; ++q) sticky[q] = 0xffffffffu;
     // One work item = HIST_UNROLL consecutive chunks; all their 16-byte loads are issued before the
     // first is consumed (one load per thread in flight left the kernel latency-bound at 3.1 TB/s).
     constexpr uint32_t HIST_UNROLL = GS_HIST_UNROLL;
     // JOINT = 0: the joint tables are given up (joint_off) — only the first digit is counted
-    auto process = [&](auto joint_tag, const uint4 t, const uint32_t x0, const bool probe) {  // t: four keys' digit words, sortable form
+    // t: four keys' digit words, sortable form; th: their high words (both)
+    auto process = [&](auto joint_tag, const uint4 t, const uint4 th, const uint32_t x0, const bool probe) {
             constexpr bool JOINT = decltype(joint_tag)::value != 0;
             GS_ABL_HIST_STREAM_ONLY(t);
             const uint32_t b[4] = {t.x, t.y, t.z, t.w};
+            const uint32_t bh[4] = {th.x, th.y, th.z, th.w};
 #if GS_HIST_REPLICAS
             if (x0 != cur_x0 || since_fold >= HIST_FOLD_CHUNKS) {  // uniform
                 fold(cur_x0);
@@ -439,11 +453,11 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             }
 #endif
 #pragma unroll
-            for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < 4; ++q) {
+            for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < NQ; ++q) {
                 if (q < np && (JOINT || q == 0)) {
                     uint32_t bin[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], q, x0);
+                    for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], bh[j], q, x0);
                     // Skew (Thearling-Smith presets, constant bytes): same-address LDS atomics serialise
                     // per lane.  Cheap probe on the first key: do >= 8 lanes share the first lane's bin?
                     // (only the first chunk of a work item probes: on every chunk the probe cost the uniform case
@@ -497,14 +511,20 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         return *q;
 #endif
     };
-    auto load_chunk = [&](uint32_t c) -> uint4 {
+    struct Chunk { uint4 w, hi; };  // the digit words of a thread's four keys (and, 64-bit keys counted in one sweep, their high words)
+    auto load_chunk = [&](uint32_t c) -> Chunk {
         if constexpr (KW == 2) {
             const uint4* p = reinterpret_cast<const uint4*>(keys) + (size_t)c * (HIST_CHUNK / 2);
             const uint4 a = ld16(p + tid), b2 = ld16(p + tid + GHIST_THREADS);
-            return uint4{word_of(a.x, a.y), word_of(a.z, a.w), word_of(b2.x, b2.y), word_of(b2.z, b2.w)};
+            if (both) {
+                const uint2 k0 = to_bits2<KT>(uint2{a.x, a.y}), k1 = to_bits2<KT>(uint2{a.z, a.w});
+                const uint2 k2 = to_bits2<KT>(uint2{b2.x, b2.y}), k3 = to_bits2<KT>(uint2{b2.z, b2.w});
+                return Chunk{uint4{k0.x, k1.x, k2.x, k3.x}, uint4{k0.y, k1.y, k2.y, k3.y}};
+            }
+            return Chunk{uint4{word_of(a.x, a.y), word_of(a.z, a.w), word_of(b2.x, b2.y), word_of(b2.z, b2.w)}, uint4{0u, 0u, 0u, 0u}};
         } else {
             const uint4 a = ld16(reinterpret_cast<const uint4*>(keys + (size_t)c * HIST_CHUNK) + tid);
-            return uint4{to_bits<KT>(a.x), to_bits<KT>(a.y), to_bits<KT>(a.z), to_bits<KT>(a.w)};
+            return Chunk{uint4{to_bits<KT>(a.x), to_bits<KT>(a.y), to_bits<KT>(a.z), to_bits<KT>(a.w)}, uint4{0u, 0u, 0u, 0u}};
         }
     };
     const uint32_t nchunks_all = (n + HIST_CHUNK - 1) / HIST_CHUNK;
@@ -522,15 +542,15 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         if (c0 + HIST_UNROLL <= nchunks && (unsigned long long)(c0 + HIST_UNROLL) * HIST_CHUNK <= n) {
             // common case: HIST_UNROLL full chunks — UNCONDITIONAL loads (conditional ones get an
             // s_waitcnt vmcnt(0) each from the compiler and end up one at a time in flight)
-            uint4 t[HIST_UNROLL];
+            Chunk t[HIST_UNROLL];
 #pragma unroll
             for (uint32_t u = 0; u < HIST_UNROLL; ++u) t[u] = load_chunk(c0 + u);
             if (GS_LIKELY(!joint_off)) {
 #pragma unroll
-                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<1>{}, t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
+                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<1>{}, t[u].w, t[u].hi, (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
             } else {
 #pragma unroll
-                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<0>{}, t[u], (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
+                for (uint32_t u = 0; u < HIST_UNROLL; ++u) process(IntTag<0>{}, t[u].w, t[u].hi, (c0 + u) * HIST_CHUNK / seg_len0, u == 0);
             }
             if (c0 == c_first) GS_HIST_STAMP(2);
             if (allow_pos && c0 == c_first && !joint_off) {
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             }
             continue;
         }
-        uint4 t[HIST_UNROLL];
+        Chunk t[HIST_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < HIST_UNROLL; ++u) {
             const uint32_t base = (c0 + u) * HIST_CHUNK;
@@ -566,13 +586,20 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             if (c0 + u < nchunks) {
                 const uint32_t x0 = base / seg_len0;  // uniform: a whole chunk lies in one position segment
                 if (base + HIST_CHUNK <= n) {
-                    if (joint_off) process(IntTag<0>{}, t[u], x0, true);
-                    else process(IntTag<1>{}, t[u], x0, true);
+                    if (joint_off) process(IntTag<0>{}, t[u].w, t[u].hi, x0, true);
+                    else process(IntTag<1>{}, t[u].w, t[u].hi, x0, true);
                 } else {
                     for (uint32_t i = base + tid; i < n; i += GHIST_THREADS) {
-                        const uint32_t kb = KW == 2 ? word_of(keys[2 * (size_t)i], keys[2 * (size_t)i + 1]) : to_bits<KT>(keys[i]);
+                        uint32_t kb, kh = 0;
+                        if constexpr (KW == 2) {
+                            const uint2 k2 = to_bits2<KT>(uint2{keys[2 * (size_t)i], keys[2 * (size_t)i + 1]});
+                            kb = (both || !word) ? k2.x : k2.y;
+                            kh = k2.y;
+                        } else {
+                            kb = to_bits<KT>(keys[i]);
+                        }
                         for (uint32_t q = 0; q < np; ++q)
-                            if (!(joint_off && q >= 1)) atomicAdd(&s_h[bin_of(kb, q, x0)], 1u);
+                            if (!(joint_off && q >= 1)) atomicAdd(&s_h[bin_of(kb, kh, q, x0)], 1u);
                     }
                 }
             }
@@ -636,6 +663,8 @@ __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t* __rest
 //   row_base[]  : first descriptor row of chain x  (chain x owns tiles_x + 1 rows)
 //   row 0 of chain x seeded INCLUSIVE with dstart[d] + sum_{x'<x} H[q][d][x']
 // ---------------------------------------------------------------------------
+// NPT: joint tables that may hold counts (4: 32-bit keys and every stand-alone use; 8: the sort of 64-bit keys); grid = passes planned
+template <int NPT>
 __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_t* desc, uint32_t* info,
                                                     uint32_t desc_stride /*words per pass*/, uint32_t n,
                                                     uint32_t seg_len0, uint32_t tile_keys,
@@ -654,24 +683,29 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     // Everything this workgroup needs from global memory, in ONE round trip: thread d's row of every joint
     // histogram (rows of passes that were not counted are zero).  The kernel is a serial step of every sort;
     // with the loads strung out behind each other it took 11 us.
-    uint32_t hq[NCH], g_all[4], g = 0, gprev = 0;
+    uint32_t hq[NCH], g_all[NPT], g = 0, gprev = 0;
+    const uint32_t np = gridDim.x;  // passes of this plan
     const uint32_t hx_skew = hist[HIST_TABLE_WORDS + HX_SKEW];
     {
-        uint32_t h[4][NCH];
+        uint32_t h[NPT][NCH];
 #pragma unroll
-        for (uint32_t qq = 0; qq < 4; ++qq)
+        for (uint32_t qq = 0; qq < NPT; ++qq)
 #pragma unroll
             for (uint32_t x = 0; x < NCH; ++x) h[qq][x] = hist[hist_index(qq, tid, x)];
 #pragma unroll
-        for (uint32_t qq = 0; qq < 4; ++qq) {
+        for (uint32_t x = 0; x < NCH; ++x) hq[x] = 0;
+#pragma unroll
+        for (uint32_t qq = 0; qq < NPT; ++qq) {
             g_all[qq] = 0;
 #pragma unroll
             for (uint32_t x = 0; x < NCH; ++x) g_all[qq] += h[qq][x];
-            if (qq == q) g = g_all[qq];
+            if (qq == q) {
+                g = g_all[qq];
+#pragma unroll
+                for (uint32_t x = 0; x < NCH; ++x) hq[x] = h[qq][x];
+            }
             if (qq + 1 == q) gprev = g_all[qq];
         }
-#pragma unroll
-        for (uint32_t x = 0; x < NCH; ++x) hq[x] = q == 0 ? h[0][x] : q == 1 ? h[1][x] : q == 2 ? h[2][x] : h[3][x];
     }
     // Position chains in every pass (PF_POS): some workgroup of the histogram kernel found the digit groups of its keys
     // uneven and stopped counting the joint tables — they are incomplete, only the first digit's position histogram
@@ -689,8 +723,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     //  constant bytes and otherwise even digits stay on this path.)
     if ((plan & 2u) && !pos) {
 #pragma unroll
-        for (uint32_t qq = 0; qq < 4; ++qq)
-            if (g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
+        for (uint32_t qq = 0; qq < NPT; ++qq)
+            if (qq < np && g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
     }
     const bool counted = !pos || q == 0;  // this pass's digit totals g and chain rows hq are complete
     if (counted && g >= (n >> 3) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
@@ -705,11 +739,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     if (plan & 2u) {
         const uint32_t triv = s_triv;
         uint32_t drop = (uint32_t)__popc(triv) & ~1u;
-        if ((plan & 1u) && drop == 4u) drop = 2u;
-        for (uint32_t qq = 0; qq < 4 && drop; ++qq)
+        if ((plan & 1u) && drop == np) drop = np - 2u;  // (a descending sort keeps one pair: its second pass reverses)
+        for (uint32_t qq = 0; qq < np && drop; ++qq)
             if ((triv >> qq) & 1u) { skip |= 1u << qq; --drop; }
     }
-    const uint32_t run_mask = ~skip & 15u;
+    const uint32_t run_mask = ~skip & ((1u << np) - 1u);
     if ((plan & 2u) && tid == 0) {
         uint32_t f = 0;
         if ((skip >> q) & 1u) f |= PF_SKIP;
@@ -1693,7 +1727,7 @@ __global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, 
     }
     if (bad_flag) atomicAdd(&report[0], (unsigned long long)bad_flag);
     if (bad_mono) atomicAdd(&report[1], (unsigned long long)bad_mono);
-    atomicAdd(&report[4 + q], (unsigned long long)(prev - (first >> 2)));
+    atomicAdd(&report[4 + (q & 3u)], (unsigned long long)(prev - (first >> 2)));  // (64-bit keys: passes q and q + 4 share a slot)
 }
 
 // ---------------------------------------------------------------------------

@@ -27,7 +27,7 @@ from ._lib import check
 MODE_KEYS_ONLY, MODE_PAIRS = 0, 1
 ORDER_ASCENDING, ORDER_DESCENDING = 0, 1
 KEY_UINT32, KEY_INT32, KEY_FLOAT32 = 0, 1, 2
-KEY_UINT64, KEY_INT64, KEY_FLOAT64 = 3, 4, 5  # 8-byte keys: two stable 4-pass rounds (low word, high word)
+KEY_UINT64, KEY_INT64, KEY_FLOAT64 = 3, 4, 5  # 8-byte keys: eight passes planned by one histogram sweep
 PAYLOAD_UINT32, PAYLOAD_INT32, PAYLOAD_FLOAT32 = 0, 1, 2
 ENTROPY_PRESET_1, ENTROPY_PRESET_2, ENTROPY_PRESET_3, ENTROPY_PRESET_4, ENTROPY_PRESET_5 = range(5)
 _ENT_LOOKUP = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201

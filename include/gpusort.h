@@ -50,8 +50,9 @@ typedef enum gs_order { GS_ORDER_ASCENDING = 0, GS_ORDER_DESCENDING = 1 } gs_ord
 /* GPUSortingD3D12/GPUSorting.h:54-60 */
 typedef enum gs_key_type {
     GS_KEY_UINT32 = 0, GS_KEY_INT32 = 1, GS_KEY_FLOAT32 = 2,
-    /* 64-bit keys (the reference has 32-bit keys only): 8-byte elements in d_keys / d_alt, sorted in
-     * two stable 4-pass rounds (low word, then high word) of the same kernels; values as for 32-bit keys.  Accepted by
+    /* 64-bit keys (the reference has 32-bit keys only): 8-byte elements in d_keys / d_alt, sorted by
+     * eight stable passes of the same kernels, planned by ONE GlobalHistogram sweep + Scan (identity passes are dropped
+     * in pairs across the whole key); values as for 32-bit keys.  Accepted by
      * gs_onesweep_sort_keys / _sort_pairs / _digit_pass (pass 0..7) and gs_validate; not by the histogram read-back,
      * the MSD split and the generator, which are 32-bit. */
     GS_KEY_UINT64 = 3, GS_KEY_INT64 = 4, GS_KEY_FLOAT64 = 5

@@ -1,6 +1,7 @@
 """64-bit keys ("+ 64-bit keys (8 passes)"; the reference sorts 32-bit keys only, so the expected
 result is the same DEFINITION on 8-byte keys: stable order by the radix-sortable bits, descending = exact reverse).
-The HIP path sorts them as two stable 4-pass rounds (low word, high word) of the 32-bit machinery; every case is
+The HIP path sorts them with the 32-bit machinery on 8-byte elements: one GlobalHistogram sweep counts eight joint tables, one
+Scan plans eight passes (round 3; GPUSORT_KEY64_SWEEPS=2: the two 4-pass rounds of round 2); every case is
 bit-exact against the oracle (and the oracle's 64-bit functions against numpy in tests/test_oracle.py)."""
 import numpy as np
 import pytest
@@ -140,7 +141,7 @@ def test_keys64_validate_counts_inversions(gpu, oracle):
 
 def test_keys64_profile_slots_are_consistent(gpu, oracle):
     """ADVICE (round 2): the second round of a 64-bit sort re-recorded the events of the first, so slots went negative and the
-    total covered half the sort.  Now round 1 is charged to slot 6 (pass 3): every slot >= 0, their sum == the total (the
+    total covered half the sort.  Passes 4..7 are charged to slot 6 (pass 3): every slot >= 0, their sum == the total (the
     slots are consecutive event pairs), and the total is about twice a 32-bit sort's."""
     import torch
     n = 1 << 22
@@ -155,5 +156,38 @@ def test_keys64_profile_slots_are_consistent(gpu, oracle):
     parts = [p[k] for k in ("clear", "global_histogram", "scan", "pass0", "pass1", "pass2", "pass3")]
     assert all(x >= 0.0 for x in parts), p
     assert abs(sum(parts) - p["total"]) < 0.02 * p["total"] + 0.005, p
-    assert p["pass3"] > 2.0 * p["pass0"], p   # pass 3 of round 0 + the whole second round
+    assert p["pass3"] > 2.0 * p["pass0"], p   # passes 3..7
     s.close()
+
+
+@pytest.mark.parametrize("sweeps", ["1", "2"])
+def test_keys64_one_plan_for_eight_passes(gpu, oracle, monkeypatch, sweeps):
+    """Round 3: ONE GlobalHistogram + Scan plans all eight passes of a 64-bit sort (the chains of pass 4 are the groups of byte 3);
+    identity passes are dropped in pairs across the whole key.  GPUSORT_KEY64_SWEEPS=2 keeps the two-round form: same results."""
+    monkeypatch.setenv("GPUSORT_KEY64_SWEEPS", sweeps)
+    rng = np.random.default_rng(88)
+    n = 300007
+    cases = {
+        "uniform": rng.integers(0, 2**64, size=n, dtype=np.uint64),
+        "40 bits": rng.integers(0, 2**40, size=n, dtype=np.uint64),                      # bytes 5..7 constant: two of them dropped
+        "bytes 2 and 5": (rng.integers(0, 256, size=n, dtype=np.uint64) << np.uint64(16)) | (rng.integers(0, 256, size=n, dtype=np.uint64) << np.uint64(40)),
+        "constant": np.full(n, 0x0123456789abcdef, dtype=np.uint64),                     # every pass an identity
+        "byte 3 skewed": (rng.integers(0, 2**32, size=n, dtype=np.uint64) << np.uint64(32)) | (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(28)) | rng.integers(0, 2**24, size=n, dtype=np.uint64),
+    }
+    for name, keys in cases.items():
+        vals = np.arange(n, dtype=np.uint64)
+        for order in (0, 1):
+            s = gpu.OneSweep(n, order, gpu.KEY_UINT64, gpu.MODE_PAIRS, 8)
+            dk, dv = _dev(keys), _dev(vals)
+            s.sort(dk, dv)
+            s.check()
+            r = s.check_state()
+            assert (r["rows_not_inclusive"], r["rows_not_monotone"], r["chains_short_of_tickets"], r["hist_words_nonzero"]) == (0, 0, 0, 0), (name, r)
+            if sweeps == "1":  # one plan: keys_per_pass[q] sums passes q and q + 4
+                ran = sum(r["keys_per_pass"]) // n
+                expect = {"uniform": 8, "40 bits": 6, "bytes 2 and 5": 2, "constant": 2 if order else 0, "byte 3 skewed": 8}[name]
+                assert ran == expect, (name, order, r)
+            rk, rv = oracle.std_sort64(keys, 0, order, vals)
+            np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint64), rk, err_msg=f"{name} order={order}")
+            np.testing.assert_array_equal(dv.cpu().numpy().view(np.uint64), rv, err_msg=f"{name} values order={order}")
+            s.close()
