@@ -126,7 +126,7 @@ constexpr uint32_t I_NEXT_SHIFT = PASS_FLAGS + 2;  // PF_POS: bit position of th
 constexpr uint32_t I_SEGLOG = PASS_FLAGS + 3;      // PF_POS: log2 of the position segments of the passes behind the first one
 constexpr uint32_t I_MODE = PASS_FLAGS + 6;        // PF_SKEW passes: the most frequent value of this pass's digit
 constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 7 + 31) / 32) * 32;
-constexpr uint32_t PF_SKEW = 1;    // some digit holds >= n/8 keys: rank with wave-aggregated adds
+constexpr uint32_t PF_SKEW = 1;    // some digit holds > n/16 keys (GS_SKEW_SHIFT): rank with wave-aggregated adds
 constexpr uint32_t PF_SKIP = 2;     // every key has the same digit AND the pass is one of an even number of such
                                     // passes: the pass is the identity permutation, its workgroups exit at once
 constexpr uint32_t PF_SRC_ALT = 4;  // an odd number of earlier passes ran: this pass reads alt and writes keys
@@ -182,6 +182,12 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && S
                      // of it back: fewer of its first reads hit the memory-side cache), profiles/r03_ab_hist_nt_loads.txt.  Measured
                      // with it and not kept: the next work item's loads in flight while this one is counted (no change: the kernel
                      // does not wait for its loads)
+#endif
+#ifndef GS_SKEW_SHIFT
+#define GS_SKEW_SHIFT 4  // a pass is ranked with wave-aggregated adds (PF_SKEW, mode digit) when some digit holds more than n >> GS_SKEW_SHIFT keys.
+                         // Rounds 1-2: 3.  Entropy preset 2 (two ANDs: digit 0 holds 10 %) fell between — plain LDS adds with a 10 % digit:
+                         // 4 takes 3 % off its keys-only sort and 6 % off its (u32, u64) pairs, nothing changes elsewhere
+                         // (profiles/r03_ab_skew_threshold.txt)
 #endif
 #ifndef GS_POS_SHARE
 #define GS_POS_SHARE 3u  // a digit group holding more than GS_POS_SHARE / 16 of a workgroup's first 16 384 keys (even: 1 / 16) sends the
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_start[MAXCH], s_end[MAXCH], s_rowbase[MAXCH + 1];
     __shared__ uint32_t s_triv;
-    __shared__ unsigned long long s_mode;     // most frequent value of this digit, if it holds more than 1/8 of the keys
+    __shared__ unsigned long long s_mode;     // most frequent value of this digit, if it holds more than 1/16 of the keys
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, q = blockIdx.x;
     uint32_t* my_info = info + q * INFO_STRIDE;
     uint32_t* my_desc = desc + (size_t)q * desc_stride;
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
             if (qq < np && g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
     }
     const bool counted = !pos || q == 0;  // this pass's digit totals g and chain rows hq are complete
-    if (counted && g >= (n >> 3) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
+    if (counted && g >= (n >> GS_SKEW_SHIFT) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
     // digit scans of this pass's totals and (for the segment starts) of the previous digit's totals
     const uint32_t incl = wave_inclusive_scan(g, lane);
     const uint32_t incl_prev = wave_inclusive_scan(gprev, lane);
@@ -807,9 +813,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     }
     if (!counted) return;  // PF_POS behind the first pass: the pass's own workgroups derive skew flag, mode digit and seeds
 
-    // skew flag for the pass: some digit holds at least 1/8 of the keys -> tiles rank with
+    // skew flag for the pass: some digit holds more than 1/16 of the keys -> tiles rank with
     // wave-aggregated adds (a dominant digit would serialise 64 lanes on one LDS counter)
-    const unsigned long long skewed = __builtin_amdgcn_ballot_w64(g >= (n >> 3) + 1u);
+    const unsigned long long skewed = __builtin_amdgcn_ballot_w64(g >= (n >> GS_SKEW_SHIFT) + 1u);
     if (lane == 0 && skewed) atomicOr(&my_info[PASS_FLAGS], PF_SKEW);
     // digit starts and chain bases
     uint32_t run = base + incl - g;  // dstart[tid]
@@ -911,7 +917,7 @@ __device__ __forceinline__ void binning_body(
                                                  // [9..14] the pass's flag/plan words
     uint32_t* s_cnt = s_misc + 16;               // POS: [NCH][256] keys written to position segment x whose next digit is d
     uint32_t* s_dstart = s_cnt + (POS == 1 ? NCH * RADIX : 0);  // POS: digit starts of this pass (from the counts of the pass before)
-    uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds >= n/8 keys, [2..3] (count << 8 | 255 - digit) max
+    uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds > n/16 keys, [2..3] (count << 8 | 255 - digit) max
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
@@ -951,7 +957,7 @@ __device__ __forceinline__ void binning_body(
                 uint32_t wbase = 0;
                 for (uint32_t w = 0; w < wave; ++w) wbase += s_misc[4 + w];
                 s_dstart[tid] = wbase + incl - G;
-                if (G >= (n >> 3) + 1u) {
+                if (G >= (n >> GS_SKEW_SHIFT) + 1u) {
                     s_pos[0] = 1u;
                     atomicMax(reinterpret_cast<unsigned long long*>(s_pos + 2), ((unsigned long long)G << 8) | (255u - tid));
                 }
