@@ -251,7 +251,7 @@ def more_block(g, n, log2, steps):
             "roofline": roofline_block(n, vb, prof, pmc_traffic(log2, vb, 0, "", tile), tile, rk),
         }
     rows = {}
-    for vb, name in ((0, "keys"), (8, "pairs_u64")):
+    for vb, name in ((0, "keys"), (4, "pairs_u32"), (8, "pairs_u64")):
         row = []
         for preset in range(5):
             gk, ms, prof, ok, (tile, rk) = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
@@ -263,7 +263,7 @@ def more_block(g, n, log2, steps):
                         "pass_frac_of_8000": (8 + 2 * vb) * n / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         rows[name] = row
     out["entropy_sweep"] = rows
-    out["entropy_sweep_note"] = ("keys-only sorts of skewed keys (presets 2-5) run on position chains in every pass (decided on the "
+    out["entropy_sweep_note"] = ("sorts of skewed keys (presets 2-5; keys-only and pairs) run on position chains in every pass (decided on the "
                                  "device: the histogram kernel finds the digit groups uneven); counting passes use 12 288-key tiles")
     # ---- 64-bit keys: two stable 4-pass rounds over 8-byte elements ----
     n64 = min(n, 1 << 27)

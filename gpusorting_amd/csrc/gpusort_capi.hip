@@ -67,19 +67,21 @@ void launch_dual(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void*
     hipLaunchKernelGGL((gs::digit_binning_dual_kernel<KT, LAST>), dim3(grid), dim3(512), 0, s, ka, kb, va, vb, desc, counters, info,
                        hsub, status, n, shift, mode);
 }
-template <int KT, bool LAST>
-void launch_pos8(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc, uint32_t* counters,
+template <int VB, int KT, bool LAST>
+void launch_posv(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc, uint32_t* counters,
                  const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
-    hipLaunchKernelGGL((gs::digit_binning_pos8_kernel<KT, LAST>), dim3(grid), dim3(512), 0, s, ka, kb, va, vb, desc, counters, info,
+    hipLaunchKernelGGL((gs::digit_binning_posv_kernel<VB, KT, LAST>), dim3(grid), dim3(512), 0, s, ka, kb, va, vb, desc, counters, info,
                        hsub, status, n, shift, mode);
 }
 #ifdef GS_MINIMAL
 const BinLauncher g_dual[2][3] = {{launch_dual<0, false>, nullptr, nullptr}, {launch_dual<0, true>, nullptr, nullptr}};
-const BinLauncher g_pos8[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+const BinLauncher g_posv[2][2][3] = {{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}};
 #else
-// (u32, u64) pairs: the position-chain form of the pass, launched beside the two plain forms [last pass][key type]
-const BinLauncher g_pos8[2][3] = {{launch_pos8<0, false>, launch_pos8<1, false>, launch_pos8<2, false>},
-                                  {launch_pos8<0, true>, launch_pos8<1, true>, launch_pos8<2, true>}};
+// pairs: the position-chain form of the pass, launched beside the plain form(s) [4- / 8-byte values][last pass][key type]
+const BinLauncher g_posv[2][2][3] = {{{launch_posv<4, 0, false>, launch_posv<4, 1, false>, launch_posv<4, 2, false>},
+                                      {launch_posv<4, 0, true>, launch_posv<4, 1, true>, launch_posv<4, 2, true>}},
+                                     {{launch_posv<8, 0, false>, launch_posv<8, 1, false>, launch_posv<8, 2, false>},
+                                      {launch_posv<8, 0, true>, launch_posv<8, 1, true>, launch_posv<8, 2, true>}}};
 const BinLauncher g_dual[2][3] = {{launch_dual<0, false>, launch_dual<1, false>, launch_dual<2, false>},
                                   {launch_dual<0, true>, launch_dual<1, true>, launch_dual<2, true>}};
 #endif
@@ -420,7 +422,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
 #endif
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
     // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
-    const bool pos_size = h->skip_passes && h->rank_mode == 1 && (vb == 0 || vb == 8) && !is_key64(kt) && h->pos_chains != 0 &&
+    const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 &&
                           n >= h->pos_min_keys;
     int shape = (h->shape_auto && n <= mid_keys(vb) && !pos_size) ? MID_SHAPE : h->shape;
     if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
@@ -434,8 +436,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // digit groups uneven, the Scan kernel plans accordingly) — every pass is then launched in both chain forms and the
     // plan says which one works.  Keys-only sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; GPUSORT_POS=0
     // switches it off.
-    const bool pos = dyn && h->rank_mode == 1 && (vb == 0 || vb == 8) && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
-                     (vb == 0 ? g_dual : g_pos8)[0][kt] != nullptr && sh.threads == 512 && sh.kpt == 32;
+    const bool pos = dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
+                     (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
+                     (vb == 4 ? sh.threads * sh.kpt == 16384 : (sh.threads == 512 && sh.kpt == 32));  // (the plan's last pass runs on 16 384-key tiles)
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
@@ -472,14 +475,14 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                 fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
-                   mode | (two_forms ? 32u : 0u) | ((pos && vb == 8) ? 64u : 0u) | exp_mode);
+                   mode | (two_forms ? 32u : 0u) | ((pos && vb != 0) ? 64u : 0u) | exp_mode);
             if (two_forms)
                 g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                         h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                         h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
                                         word * 32 + p * 8, mode | 16u | ((pos && vb == 8) ? 64u : 0u));
-            if (pos && vb == 8)  // 8-byte values: the position-chain form is a third launch (the plan's flags pick one of the three)
-                g_pos8[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+            if (pos && vb != 0)  // pairs: the position-chain form is a launch of its own (the plan's flags pick one of the two or three)
+                g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
                                    (mode & ~4u) | 64u);

@@ -847,7 +847,7 @@ struct BinCfg {
     // the same loop — no second staging round, no saved positions/digits, two barriers fewer per tile
     // (8-byte values the same way need a 512 x 24 tile, 12 288 pairs x 12 B = 144 KiB in two LDS arrays: measured
     //  5.975 vs 6.014 ms, not worth a shape of its own; the code path stays generic in VB)
-    static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4 && KW == 1;
+    static constexpr bool FUSED = GS_FUSED_PAIRS && VB == 4 && KW == 1 && POS == 0;  // (the position-chain forms keep their LDS for the count table)
     // VR = 2: 8-byte values of 4-byte keys go through the stage in TWO rounds of TILE / 2 values: the stage stays at the
     // 4 bytes per key the keys need, and a 16 384-pair tile leaves room for a second workgroup on the CU.  Measured
     // (profiles/r02_ab_value_rounds.txt, 2^28 (u32, u64) pairs): uniform keys +5 % per pass (two predicated staging
@@ -895,8 +895,8 @@ __device__ __forceinline__ void binning_body(
                     (checked first)*/) {
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
-    static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || (VB == 8 && VR == 2))),
-                  "the position-chain forms exist for 32-bit keys, keys-only or with 8-byte values (two staging rounds), LDS-atomic ranking");
+    static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || VB == 4 || (VB == 8 && VR == 2))),
+                  "the position-chain forms exist for 32-bit keys, keys-only, with 4-byte values (staged behind the keys) or with 8-byte values (two staging rounds), LDS-atomic ranking");
     using V = typename ValT<VB>::type;
     constexpr int WAVES = Cfg::WAVES;
     constexpr uint32_t TILE = Cfg::TILE;
@@ -1684,14 +1684,16 @@ __global__ __launch_bounds__(512, 4) void digit_binning_dual_kernel(
 // (u32 key, u64 value) pairs that the Scan kernel may plan on position chains: the position-chain form as a launch of its own
 // (persistent workgroups, values staged in two rounds through the keys' stage) beside the two plain forms, each of which exits
 // on the plan's flags (mode bit 6) — one kernel holding all three would need the one-round form's 140 KiB of LDS.
-template <int KT, bool LAST>
-__global__ __launch_bounds__(512, 4) void digit_binning_pos8_kernel(
+// VB = 4 (round 3, late): the same for (u32, u32) pairs — their plain form stages key and value together (128 KiB: no room for the
+// count table), this one stages the values behind the keys through the keys' stage.
+template <int VB, int KT, bool LAST>
+__global__ __launch_bounds__(512, 4) void digit_binning_posv_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
     uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
-    constexpr int KPT = LAST ? 32 : 24, POS = LAST ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<512, KPT, 8, 1, 2, POS>::LDS_BYTES];
+    constexpr int KPT = LAST ? 32 : 24, POS = LAST ? 2 : 1, VR = VB == 8 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<512, KPT, VB, 1, VR, POS>::LDS_BYTES];
     static_assert(sizeof(s_raw) * 2 <= 160 * 1024, "two workgroups per CU");
-    binning_body<512, KPT, 8, KT, 1, 2, POS, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
+    binning_body<512, KPT, VB, KT, 1, VR, POS, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
 }
 
 // ---------------------------------------------------------------------------

@@ -593,8 +593,7 @@ def _heavy_inputs(oracle, n):
 def test_skewed_keys_take_position_chains(gpu, oracle, vb, kt, order, monkeypatch, routing):
     """Skewed keys (uneven digit groups): the histogram kernel notices, the Scan kernel plans every pass on position
     chains, each pass counts the next one's digit per output segment while it scatters.  The library allows that plan
-    from 2^25 keys up; GPUSORT_POS_MIN_LOG2 lowers the threshold for this test (keys-only sorts; the pairs cases run
-    the digit-group chains on the same inputs)."""
+    from 2^25 keys up; GPUSORT_POS_MIN_LOG2 lowers the threshold for this test (keys-only sorts and pairs of both value widths)."""
     if routing != "position-chains":
         monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "22")
     n = (1 << 22) + 54321
