@@ -189,3 +189,36 @@ def test_2pow26_pairs_ballot_ranking_exact_vs_oracle(gpu, oracle):
 def test_2pow27_pairs_descending_float_exact_vs_oracle(gpu, oracle):
     """The reference's middle size (2^27) through typed keys + descending order with value = index."""
     _exact_case(gpu, oracle, 27, 1, 4, order=1, kt=2)
+
+
+def test_2pow28_pairs_u32_skewed_index_exact_vs_oracle(gpu, oracle):
+    """configs[2] at entropy preset 4 with value = index: (u32, u32) pairs of skewed keys run the position-chain plan at its default
+    threshold (round 3: values staged behind the keys in that plan's kernels) — keys and the stable payload order, bit-exact."""
+    _exact_case(gpu, oracle, 28, 3, 4)
+
+
+def test_2pow27_uint64_keys_exact(gpu):
+    """64-bit keys at full size (SURVEY.md 8f N2): 2^27 uniform uint64 keys, one histogram sweep + eight passes, against numpy's sort;
+    then keys below 2^40 (three constant bytes: two passes dropped) by the order-aware Validate and a permutation checksum."""
+    import torch
+    n = 1 << 27
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2027)
+    dk = torch.randint(-(1 << 63), (1 << 63) - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+    keys = dk.cpu().numpy().view(np.uint64).copy()
+    s = gpu.OneSweep(n, key_type=gpu.KEY_UINT64)
+    s.sort(dk)
+    s.check()
+    keys.sort()
+    assert bool((dk == torch.from_numpy(keys.view(np.int64)).cuda()).all().item()), "sorted 64-bit keys differ from numpy's"
+    del keys
+    dk &= (1 << 40) - 1
+    dk = dk[torch.randperm(n, device="cuda", generator=g)]
+    before = (int(dk.sum().item()), int((dk % 1000003).sum().item()))
+    s.sort(dk)
+    s.check()
+    r = s.check_state()
+    assert sum(r["keys_per_pass"]) == 6 * n, r        # bytes 5..7 constant: one pair of passes dropped
+    assert gpu.validate(dk, key_type=gpu.KEY_UINT64) == 0
+    assert (int(dk.sum().item()), int((dk % 1000003).sum().item())) == before
+    s.close()
