@@ -5,12 +5,13 @@
 // 2^14 and 2^20 keys the six-launch pipeline is a ~50 us plateau of launch and tile latencies (profiles/
 // r01_size_and_entropy_sweep_v3.txt) — four global passes of >= 9 us each whatever the size.  At these sizes the keys
 // of one top-byte value fit ONE workgroup's LDS, so the sort is done as
-//   K1 mid_msd_kernel     one MSD pass: every workgroup (one tile each — 8192 keys, 16 384 above 2^20, 32 768 above 2^21 —
-//                         at most 128) ranks its tile by the TOP byte, publishes its 256 counts, waits until the count
-//                         table is complete, derives every bucket's start and its own offsets from it, and scatters its
-//                         tile into the alt buffer (stable);
+//   K1 mid_msd_kernel     one MSD pass: every workgroup (one tile each — 8192 keys, 16 384 above 2^20; at most 128 tiles, 256
+//                         above 2^21) ranks its tile by the TOP byte, publishes its 256 counts, waits until the count
+//                         table is complete, derives every bucket's start and its own offsets from it (the whole workgroup
+//                         reads the table: 16-byte sc1 loads), and scatters its tile into the alt buffer (stable);
 //   K2 bucket_sort_kernel one workgroup per top-byte bucket sorts it on the remaining 24 bits entirely in LDS (three
-//                         stable passes, as the single-tile sort) and writes it to its final place in the key buffer.
+//                         stable passes, as the single-tile sort; the bucket spread evenly over the workgroup's waves) and
+//                         writes it to its final place in the key buffer.
 // Two global passes instead of four (20 B/key instead of 36), two launches instead of six.  Same result as the LSD
 // sort: (stable by top byte) o (stable sort of each bucket by the low 24 bits) == stable sort by the whole key.
 // If a bucket would not fit a workgroup (skewed top byte) every workgroup sees that in the SAME count table and K1
@@ -36,10 +37,10 @@
 
 namespace gs {
 
-// Three tile shapes, always at most 128 tiles; a top-byte bucket must fit ONE tile (K2 sorts it in LDS):
-//   512 x 16 =  8 192 keys  n <= 2^20   every value width
-//   512 x 32 = 16 384 keys  n <= 2^21   keys-only and 4-byte values (stage 64 + 64 KiB)
-//  1024 x 32 = 32 768 keys  n <= 2^22   keys-only (stage 128 KiB)
+// Three classes by the bucket K2's workgroup can hold (a top-byte bucket must fit it); K1's tiles:
+//   K2 512 x 16 =  8 192 keys  n <= 2^20   every value width                                      K1 <= 128 tiles of  8 192
+//   K2 512 x 32 = 16 384 keys  n <= 2^21   keys-only and 4-byte values (stage 64 + 64 KiB)        K1 <= 128 tiles of 16 384
+//   K2 1024 x 32 = 32 768 keys n <= 2^22   keys-only (stage 128 KiB)                              K1 <= 256 tiles of 16 384
 constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // the smallest shape
 constexpr uint32_t MID_MAX_TILES = 256;                                                // (the smallest shape stops at 128: one launch wave of half the CUs)
 constexpr uint32_t MID_MAX_KEYS = 128 * MID_TILE;                                      // 2^20: limit of the smallest shape
