@@ -66,6 +66,15 @@ __host__ __device__ constexpr uint32_t mid_tag(uint32_t epoch, uint32_t step) { 
 #ifndef GS_MID_ADOPT_SPINS
 #define GS_MID_ADOPT_SPINS 64u  // polls (~1-2 us each) on a missing count row before the waiter looks at the tile's claim word
 #endif
+// experiment builds (GS_EXP & 4096): phase stamps (10 ns ticks) of workgroup 7 of K1 / of K2 into the status words 16.. / 24..
+// (tools/r03_mid_phases.py)
+#if (GS_EXP & 4096)
+#define GS_MID_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 7) status[16 + (i)] = (uint32_t)wall_clock64(); } while (0)
+#define GS_MID_STAMP2(i) do { if (threadIdx.x == 0 && blockIdx.x == 7) const_cast<uint32_t*>(status)[24 + (i)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define GS_MID_STAMP(i) do { } while (0)
+#define GS_MID_STAMP2(i) do { } while (0)
+#endif
 #ifndef GS_FAULT_MID_ABSENT
 #define GS_FAULT_MID_ABSENT(block) false  // fault injection: this workgroup of K1 behaves as if it had never been dispatched
 #endif
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     uint32_t* aflag = scratch + MID_AFLAG;
     uint32_t* bflag = scratch + MID_BFLAG;
     if (GS_FAULT_MID_ABSENT(blockIdx.x)) return;
+    GS_MID_STAMP(0);
 
     uint32_t key[KPT];
     V val[VB != 0 ? KPT : 1];
@@ -355,13 +365,17 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     // ---- MSD step on the top byte ----
     uint32_t* table0 = scratch + MID_TABLE;
     uint32_t* table1 = table0 + MID_MAX_TILES * RADIX;
+    GS_MID_STAMP(1);  // own tile loaded
     rank_and_publish(24, table0, mid_tag(epoch, 0), true);
+    GS_MID_STAMP(2);  // ranked, counts published
     if (!wait_flags(aflag, mid_tag(epoch, 0), true, 24, table0)) return;
+    GS_MID_STAMP(3);  // every row there
     if (!own_in_regs) {  // an adoption used the registers: back to the own tile
         load_tile(blockIdx.x, keys, vals_, false);
         rank_and_publish(24, table0, 0u, false);
     }
     const uint32_t G = bases(table0);
+    GS_MID_STAMP(4);  // bases
     const bool lsd_route = uni(s_max) > (uint32_t)BUCKET_CAP;  // a bucket K2 could not hold; the same table everywhere: the same decision everywhere
     __syncthreads();                      // everybody has read s_max before the next ranking resets it
     // K2's plan, written by whoever owns tile 0 (its own workgroup, or the one that adopted it) while that tile is at hand
@@ -385,7 +399,9 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
             }
             if (cur_tile == 0u) write_plan();
             stage(24);
+            GS_MID_STAMP(5);  // staged
             scatter(24, alt, valt_, false, false);
+            GS_MID_STAMP(6);  // scatter issued
         }
         return;
     }
@@ -448,6 +464,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
     const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)scratch[MID_CTR]) + 1u;  // (advanced when ALL of K2 is through)
     // K2's licence: the plan below is THIS call's (epoch) and no workgroup of K1 gave up (status).  Otherwise the bucket
     // table may be an earlier call's — of another n — and nothing may be written.
+    GS_MID_STAMP2(0);
     bool work = scratch[MID_EPOCH] == epoch && *status == STATUS_OK && scratch[MID_ROUTE] == 0u;  // (route 1: K1 ran the LSD passes itself)
     const uint32_t start = scratch[MID_BSTART + blockIdx.x], count = scratch[MID_BCOUNT + blockIdx.x];
     if (count == 0u || count > TILE || start > n || count > n - start) work = false;  // (the last three cannot happen with a valid plan)
@@ -471,9 +488,11 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
 #pragma unroll
     for (int i = 0; i < KPT; ++i)
         if ((uint32_t)i < kpt) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
+    GS_MID_STAMP2(1);  // bucket loaded
     // a bucket of 64 keys or fewer could stop earlier; the three passes on LDS cost a few microseconds at any size
 #pragma unroll 1
     for (uint32_t shift = 0; shift < 24; shift += 8) {
+        GS_MID_STAMP2(2 + (shift >> 3));  // LDS pass starts
         for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
         __syncthreads();
         uint32_t off[KPT / 2];
@@ -516,6 +535,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
             if constexpr (VB != 0) val[i] = s_vstage[my_base + i * 64u];
         }
     }
+    GS_MID_STAMP2(5);  // three passes done
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t slot = my_base + i * 64u;
@@ -526,6 +546,7 @@ __global__ __launch_bounds__(THREADS_) void bucket_sort_kernel(uint32_t* keys, c
             if constexpr (VB != 0) reinterpret_cast<V*>(vals_)[o] = val[i];
         }
     }
+    GS_MID_STAMP2(6);  // stores issued
     }  // work
     // the call is over when every workgroup of K2 has read the epoch: the last one to finish advances it
     __syncthreads();
