@@ -395,7 +395,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     // Eight threads share the 32 replicas of a counter pair (one 16-byte read each, conflict-free), sum them with three
     // butterfly steps, and the first of them owns the two bins they go to.  (One LDS add per non-empty replica word had the
     // 32 replicas of a pair meet on ONE address: 128 wave-adds of 32 serial steps each, 9 us per fold — half of this
-    // kernel's fixed cost at mid sizes and 3 % of it at 2^28, profiles/r03_hist_phases.txt.)
+    // kernel's fixed cost at mid sizes and 3 % of it at 2^28, profiles/r03_mid_route_v3_and_hist_fold.txt.)
     auto fold = [&](uint32_t x) {
         __syncthreads();
         if (x != 0xffffffffu) {
