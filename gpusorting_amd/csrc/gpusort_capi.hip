@@ -185,7 +185,7 @@ struct gs_onesweep {
     gs_key_type msd_kt;
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
     // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
-    uint32_t last_n, last_tile, last_p0, last_np, last_dyn, last_desc_stride;
+    uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
     bool exp_keep_desc;  // experiment builds (GS_EXP & 1024): the histogram kernel leaves the descriptor rows alone
 };
@@ -261,20 +261,26 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) !
 // (pass p0 over position segments, later passes over digit groups of the previous digit).
 struct PassPlan {
     uint32_t grid, desc_stride;
+    uint32_t grid0;  // grid of the plan's first pass (shape0_index)
 };
+// shape0_index >= 0: the plan's first pass runs on that (larger) tile shape, the others on shape_index
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
-                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0) {
+                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0, int shape0_index = -1) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
-    const uint32_t tiles = div_up(n, tile);
+    const uint32_t tile0 = shape0_index < 0 ? tile : (uint32_t)g_shapes[shape0_index].threads * g_shapes[shape0_index].kpt;
+    const uint32_t tiles = div_up(n, tile < tile0 ? tile : tile0);
     // every chain: its tiles (+1 partial) + row 0; bit 2 of the plan: the sort may end up on the (smaller) position-chain tiles
     const uint32_t rows = ((scan_plan & 4u) && POS_TILE < tile ? div_up(n, POS_TILE) : tiles) + 2 * gs::MAXCH + 2;
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
-    // position segments of the first pass: equal, multiples of the histogram chunk
-    const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), gs::HIST_CHUNK) * gs::HIST_CHUNK;
+    // position segments of the first pass: equal, multiples of the histogram chunk — and of the first pass's tile where that is a
+    // multiple of the chunk (every shape the library picks): its chains then consist of whole tiles, 16 partial tiles fewer (at
+    // mid sizes one launch round fewer: 2^24 keys are 1024 tiles of 16 384, two rounds on 512 slots)
+    const uint32_t seg_unit = (tile0 % gs::HIST_CHUNK == 0u) ? tile0 : gs::HIST_CHUNK;
+    const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), seg_unit) * seg_unit;
     // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
     // The histogram kernel ACCUMULATES into HIST and relies on it being zero between calls (the first pass
     // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
@@ -293,14 +299,15 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
     if (np > 4)  // 64-bit keys: all eight passes from one sweep
         hipLaunchKernelGGL(gs::scan_kernel<8>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE, tile0);
     else
         hipLaunchKernelGGL(gs::scan_kernel<4>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE);
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE, tile0);
     if (rec) GS_HIP(hipEventRecord(h->ev[3], s));
-    plan->grid = tiles + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
+    plan->grid = div_up(n, tile) + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
+    plan->grid0 = div_up(n, tile0) + gs::MAXCH + 1;
     plan->desc_stride = desc_stride;
-    h->last_n = n; h->last_tile = tile; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u;
+    h->last_n = n; h->last_tile = tile; h->last_tile0 = tile0; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u;
     h->last_desc_stride = desc_stride;
     return GS_OK;
 }
@@ -429,6 +436,14 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
+    // Mid sizes, keys-only (2^22 < n <= 2^25: the 8192-key tile): the FIRST pass runs on the 16 384-key tile.  Its position segments are
+    // whole tiles (prologue), so 2^24 keys are exactly 1024 tiles — two launch rounds on the 512 slots of that shape instead of three
+    // rounds of 8192-key tiles on 768 — and its input is cold, which the larger tile streams better; the later passes' chains are
+    // digit groups with a partial tile at each end, which overflow the round.  GPUSORT_FIRST_PASS_BIG=0 switches it off (A/B).
+    static const bool first_big_env = !(getenv("GPUSORT_FIRST_PASS_BIG") && atoi(getenv("GPUSORT_FIRST_PASS_BIG")) == 0);
+    const int shape0 = (first_big_env && h->shape_auto && shape == MID_SHAPE && vb == 0 && !is_key64(kt) && n > (1u << 22) &&
+                        g_shapes[0].fn[h->rank_mode][0][kt] != nullptr) ? 0 : shape;
+    BinLauncher fn0 = g_shapes[shape0].fn[h->rank_mode][vb_index(vb)][kt];
     // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
     // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
     const uint32_t dyn = h->skip_passes ? 2u : 0u;
@@ -459,7 +474,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word);
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0);
         if (st != GS_OK) return st;
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
         for (uint32_t p = 0; p < NP; ++p) {
@@ -472,7 +487,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
             else
-                fn(s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+                (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
                    mode | (two_forms ? 32u : 0u) | ((pos && vb != 0) ? 64u : 0u) | exp_mode);
@@ -591,7 +606,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->pinned = nullptr;
     h->trace_buf = nullptr;
     h->msd_keys = nullptr;
-    h->last_n = h->last_tile = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
+    h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
     h->hist_dirty = false;
     h->exp_keep_desc = false;
     h->msd_n = h->msd_grid = 0;
@@ -785,7 +800,7 @@ gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream)
     if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) ret = GS_ERR_HIP;
     if (ret == GS_OK) {
         hipLaunchKernelGGL(gs::check_state_kernel, dim3(gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
-                           h->last_tile, 0u, h->last_dyn, d, POS_TILE);
+                           h->last_tile, 0u, h->last_dyn, d, POS_TILE, h->last_tile0);
         if (hipMemcpyAsync(report, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             ret = GS_ERR_HIP;

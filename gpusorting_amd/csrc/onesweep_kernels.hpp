@@ -676,7 +676,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
                                                     uint32_t seg_len0, uint32_t tile_keys,
                                                     uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip identity
                                                                     passes, bit2 (with bit1): position chains in every pass allowed*/,
-                                                    uint32_t tile_keys_pos /*tile of the position-chain kernels (bit2)*/) {
+                                                    uint32_t tile_keys_pos /*tile of the position-chain kernels (bit2)*/,
+                                                    uint32_t tile_keys0 /*tile of the plan's first pass (mid sizes: the first pass runs on the
+                                                                          larger tile, its position segments are whole tiles)*/) {
     __shared__ uint32_t s_wtot[2][4];
     __shared__ uint32_t s_cum[RADIX + 1];
     __shared__ uint32_t s_start[MAXCH], s_end[MAXCH], s_rowbase[MAXCH + 1];
@@ -793,7 +795,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     if (wave == 0) {
         uint32_t rows = 0;
         // (PF_POS: the passes that count for a successor run on the smaller tile, the last one on the full-size tile)
-        if (lane < MAXCH) rows = chain_tiles(s_start[lane], s_end[lane], (pos && q != 3u) ? tile_keys_pos : tile_keys) + 1u;
+        if (lane < MAXCH)
+            rows = chain_tiles(s_start[lane], s_end[lane], (pos && q != 3u) ? tile_keys_pos : (q == 0u ? tile_keys0 : tile_keys)) + 1u;
         const uint32_t rincl = wave_inclusive_scan(rows, lane);
         if (lane <= MAXCH) s_rowbase[lane] = rincl - rows;
     }
@@ -1707,7 +1710,8 @@ __global__ __launch_bounds__(512, 4) void digit_binning_posv_kernel(
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, uint32_t desc_stride, uint32_t tile_keys,
                                                            uint32_t p0, uint32_t dyn, unsigned long long* report,
-                                                           uint32_t tile_keys_pos /*tile of a sort planned with PF_POS*/) {
+                                                           uint32_t tile_keys_pos /*tile of a sort planned with PF_POS*/,
+                                                           uint32_t tile_keys0 /*tile of the plan's first pass*/) {
     const uint32_t tid = threadIdx.x, q = blockIdx.y, chain = blockIdx.x;
     if (q == 0 && chain == 0) {
         uint32_t nz = 0;
@@ -1718,7 +1722,7 @@ __global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, 
     if (dyn && (info[PASS_FLAGS] & PF_SKIP)) return;  // an identity pass that was dropped: nothing ran
     if (chain >= info[I_NCH]) return;
     const uint32_t tiles = chain_tiles(info[I_START + chain], info[I_END + chain],
-                                       ((info[PASS_FLAGS] & PF_POS) && q != 3u) ? tile_keys_pos : tile_keys);
+                                       ((info[PASS_FLAGS] & PF_POS) && q != 3u) ? tile_keys_pos : (q == 0u ? tile_keys0 : tile_keys));
     if (tiles == 0) return;
     const uint32_t* rows = slab + SLAB_DESC + (size_t)q * desc_stride + (size_t)info[I_ROW + chain] * RADIX;
     if (tid == 0 && slab[SLAB_COUNTERS + ((p0 + q) * COUNTERS_PER_PASS + chain) * COUNTER_STRIDE] < tiles)

@@ -608,6 +608,17 @@ def test_skewed_keys_take_position_chains(gpu, oracle, vb, kt, order, monkeypatc
             np.testing.assert_array_equal(ov, rv, err_msg=name)
 
 
+@pytest.mark.parametrize("kt,order", [(0, 0), (1, 1), (2, 0)])
+def test_mid_size_first_pass_on_the_larger_tile(gpu, oracle, kt, order):
+    """2^22 < n <= 2^25 keys-only on the general path: the first pass runs on 16 384-key tiles over tile-aligned position
+    segments, the later passes on 8192-key tiles (round 3) — two tile shapes in one plan.  Exact, and the scan state adds up
+    (every pass accounts for n keys with ITS tile size: _assert_scan_state in _gpu_sort)."""
+    for n in ((1 << 22) + 1, (1 << 23) + 777, 3 * (1 << 22) - 5):
+        keys = oracle.init_random(n, 23 + kt, 0)
+        ok, _ = _gpu_sort(gpu, keys, kt, order)
+        np.testing.assert_array_equal(ok, oracle.std_sort(keys, kt, order), err_msg=f"n={n} kt={kt} order={order}")
+
+
 def _fuzz_keys(rng, oracle, n):
     kind = int(rng.integers(0, 8))
     u = oracle.init_random(n, int(rng.integers(1, 1 << 30)), 0)
