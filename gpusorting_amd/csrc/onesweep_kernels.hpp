@@ -862,7 +862,7 @@ struct BinCfg {
     // pass's digit per output position segment while they scatter — table [NCH][256] kept for the workgroup's whole life —
     // and derive the pass's digit starts from the counts of the pass before (256 words + 8)
     // POS = 2: the same without the counting and its table — the last pass of such a sort, on full-size tiles
-    static constexpr int POS_BYTES = POS == 1 ? (NCH * RADIX * 4 + RADIX * 4 + 32) : POS == 2 ? (RADIX * 4 + 32) : 0;
+    static constexpr int POS_BYTES = POS == 1 ? (NCH * RADIX * 4 + RADIX * 4 + 128) : POS == 2 ? (RADIX * 4 + 32) : 0;
     static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + POS_BYTES + GS_ABL_COUNT_LDS;
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
@@ -920,7 +920,8 @@ __device__ __forceinline__ void binning_body(
                                                  // [9..14] the pass's flag/plan words
     uint32_t* s_cnt = s_misc + 16;               // POS: [NCH][256] keys written to position segment x whose next digit is d
     uint32_t* s_dstart = s_cnt + (POS == 1 ? NCH * RADIX : 0);  // POS: digit starts of this pass (from the counts of the pass before)
-    uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds > n/16 keys, [2..3] (count << 8 | 255 - digit) max
+    uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds > n/16 keys, [2..3] (count << 8 | 255 - digit) max;
+                                                           // POS == 1: [4] the next digit this workgroup does NOT count (see count_next), [5] its election, [8..23] keys written per output segment
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
@@ -943,8 +944,10 @@ __device__ __forceinline__ void binning_body(
     uint32_t pos_mode = 0xffffffffu, cnt_guess = 0xffffffffu;
     const uint32_t* cn_in = hsub + (shift_full >> 3) * HSUB_STRIDE;
     if constexpr (POS != 0) {
-        if constexpr (POS == 1)
+        if constexpr (POS == 1) {
             for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) s_cnt[i] = 0;
+            if (tid < 32u && tid >= 4u) s_pos[tid] = tid == 4u ? 0xfffffffeu : 0u;  // [4]: not chosen yet
+        }
         pos_derived = shift_full != 0u;  // (the first pass of a PF_POS sort is never dropped: its chains come from the Scan kernel)
         if (pos_derived) {
             uint32_t G = 0, incl = 0;
@@ -1435,6 +1438,21 @@ __device__ __forceinline__ void binning_body(
     GS_TRACE(5);
     GS_TRACE_END(chain);
     if (uni(s_misc[2]) != 0u) break;  // look-back gave up (timeout or poisoned predecessor): write nothing
+    if constexpr (POS == 1) {
+        // keys this tile writes per output position segment, from the digit threads' run geometry (ONE LDS add per run, two for the
+        // rare run across a segment boundary): what count_next leaves out — the workgroup's hot next digit — is recovered from these
+        // totals when the table is flushed
+        if (next_shift != 0xffffffffu && tid < RADIX && tile_total != 0u) {
+            const uint32_t x0 = prev >> seglog, x1 = (prev + tile_total - 1u) >> seglog;
+            if (x0 == x1) {
+                atomicAdd(&s_pos[8u + x0], tile_total);
+            } else {  // (a run is shorter than a segment: two segments at most)
+                const uint32_t first = ((x0 + 1u) << seglog) - prev;
+                atomicAdd(&s_pos[8u + x0], first);
+                atomicAdd(&s_pos[8u + x1], tile_total - first);
+            }
+        }
+    }
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----
@@ -1455,29 +1473,40 @@ __device__ __forceinline__ void binning_body(
     // ---- POS: count the next pass's digit per output position segment while scattering.  One LDS add per key on the
     // workgroup's table [segment][digit] (flushed once, when the workgroup runs out of tiles); the stage is ordered by
     // THIS digit, so the lanes of one scatter instruction write one or two runs — one segment, with few exceptions — and
-    // their next digits are what collides: the lanes holding the wave's guess of the most frequent next digit are counted
-    // with ONE add of their popcount by the first of them, everybody else adds 1 (plain adds cost 0.23 / 0.57 ms per pass
+    // their next digits are what collides.  The workgroup therefore leaves ONE next digit out — its guess of the most frequent
+    // one, fixed at its first tile — and recovers that digit's counts at the flush from the number of keys it wrote to each segment
+    // (known per run from the digit threads: s_pos[8..]).  (Round 3, first form: the lanes holding a per-wave guess counted with ONE
+    // add of a ballot's popcount — exact, but two ballots, a readlane and a popcount per key: 153 M VALU + 97 M SALU instructions per
+    // counting pass against 59 M + 29 M for the plain pass, profiles/r03_rocprofv3_pmc_sq_insts.txt.  Plain adds cost 0.23 / 0.57 ms per pass
     // at entropy presets 3 / 5 against 0.01 ms for uniform keys, profiles/r03_next_digit_count_cost.txt).
     auto count_next = [&](uint32_t kb, uint32_t o, bool valid) {
         const uint32_t dn = (kb >> (next_shift & 31u)) & 255u;
-        const uint32_t bin = ((o >> seglog) << 8) + dn;
-        const bool hot = valid && dn == cnt_guess;
-        const unsigned long long H = __builtin_amdgcn_ballot_w64(hot);
-        uint32_t add = valid ? 1u : 0u;
-        if (H) {  // uniform
-            const uint32_t first = (uint32_t)__builtin_ctzll(H);
-            const uint32_t bin_first = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)first);
-            if (__builtin_amdgcn_ballot_w64(hot && bin != bin_first) == 0ull)  // one segment: one add for all of them
-                add = hot ? (lane == first ? (uint32_t)__popcll(H) : 0u) : add;
-        }
-        if (add) atomicAdd(&s_cnt[bin], add);
+        if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 8) + dn], 1u);
     };
     const bool counting = POS == 1 && next_shift != 0xffffffffu;  // uniform
     if constexpr (POS == 1) {
-        if (counting) {  // the wave's guess: the first lane's next digit, if at least 8 lanes of the first 64 slots share it
-            const uint32_t k0 = s_stage[wave * 64u + lane];
-            const uint32_t d0 = (k0 >> (next_shift & 31u)) & 255u, c0 = uni(d0);
-            if (__popcll(__builtin_amdgcn_ballot_w64(d0 == c0)) >= 8) cnt_guess = c0;
+        if (counting) {
+            // the digit this workgroup leaves out, chosen ONCE: a next digit that at least 8 of 64 staged keys share (every wave looks at 64
+            // of its own, eight candidate lanes each; the most frequent find wins); a tile without such a digit leaves the choice to the next one
+            if (uni(s_pos[4]) == 0xfffffffeu) {
+                __syncthreads();  // (everybody has read the word)
+                {
+                    const uint32_t d0 = (s_stage[wave * (TILE / WAVES) + lane] >> (next_shift & 31u)) & 255u;
+                    uint32_t best = 0;  // (popcount << 8) | digit
+#pragma unroll
+                    for (int c = 0; c < 64; c += 8) {
+                        const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)d0, c);
+                        const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d0 == cand));
+                        best = ((pc << 8) | cand) > best ? ((pc << 8) | cand) : best;
+                    }
+                    if (lane == 0 && (best >> 8) >= 8u) atomicMax(&s_pos[5], best);
+                }
+                __syncthreads();
+                if (tid == 0 && s_pos[5] != 0u) s_pos[4] = s_pos[5] & 255u;
+                __syncthreads();
+            }
+            cnt_guess = uni(s_pos[4]);
+            if (cnt_guess == 0xfffffffeu) cnt_guess = 0xffffffffu;  // (no digit left out in this tile: nothing to recover for it)
         }
     }
 
@@ -1643,6 +1672,16 @@ __device__ __forceinline__ void binning_body(
         const uint32_t ns = uni(info[I_NEXT_SHIFT]);
         if ((mode & 2u) && ns != 0xffffffffu) {
             __syncthreads();
+            const uint32_t left_out = uni(s_pos[4]);
+            if (left_out < RADIX) {  // the digit count_next skipped: keys written to the segment minus everything that was counted
+                for (uint32_t x = wave; x < NCH; x += WAVES) {
+                    uint32_t sum = 0;
+                    for (uint32_t d = lane; d < RADIX; d += 64u) sum += d == left_out ? 0u : s_cnt[x * RADIX + d];
+                    sum = wave_reduce_sum(sum);
+                    if (lane == 0) s_cnt[x * RADIX + left_out] = s_pos[8u + x] - sum;
+                }
+                __syncthreads();
+            }
             uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
             for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
                 const uint32_t v = s_cnt[i];
