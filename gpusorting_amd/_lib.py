@@ -49,10 +49,12 @@ _PROTOS = [
     ("gs_onesweep_set_small_path", _int, [_vp, _int]),
     ("gs_onesweep_set_skip_passes", _int, [_vp, _int]),
     ("gs_onesweep_set_mid_path", _int, [_vp, _int]),
+    ("gs_onesweep_set_plan", _int, [_vp, _int]),
     ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_set_trace", _int, [_vp, _vp]),
     ("gs_debug_check_state", _int, [_vp, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_poke_status", _int, [_vp, _u32, _vp]),
+    ("gs_debug_read_slab", _int, [_vp, _u32, _u32, _u32p, _vp]),
     ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
     ("gs_onesweep_msd_prepare", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),

@@ -14,6 +14,7 @@
 #include "../../include/gpusort.h"
 #include "onesweep_kernels.hpp"
 #include "mid_kernels.hpp"
+#include "ls_kernels.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,38 @@ constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb
 // workgroup per CU), up to 2^23 with 4-byte values (1024 x 16 wins from 2^24)
 inline uint32_t mid_keys(uint32_t vb) { return vb == 4 ? (1u << 23) : (1u << 25); }
 
+// ---- local-sort plan (ls_kernels.hpp): four launches, no histogram sweep ----
+using LsFirstLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, uint32_t* runs_t, uint32_t* slices, uint32_t* slab,
+                                 size_t zero_end, uint32_t n, uint32_t plan);
+using LsPassLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, const uint32_t* runs, const uint32_t* eprefix, const uint32_t* stab,
+                                uint32_t nt_pad, uint32_t* slab, uint32_t* slices, uint32_t desc_off, uint32_t n, uint32_t pass, uint32_t mode);
+template <int KT>
+void launch_ls_first(hipStream_t s, uint32_t grid, const uint32_t* in, uint32_t* out, uint32_t* runs_t, uint32_t* slices, uint32_t* slab,
+                     size_t zero_end, uint32_t n, uint32_t plan) {
+    hipLaunchKernelGGL((gs::ls_first_kernel<KT>), dim3(grid), dim3(gs::LS_THREADS), 0, s, in, out, runs_t, slices, slab, zero_end, n, plan);
+}
+template <int KT, bool GATHER, bool COUNT>
+void launch_ls_pass(hipStream_t s, uint32_t grid, const uint32_t* in, uint32_t* out, const uint32_t* runs, const uint32_t* eprefix, const uint32_t* stab,
+                    uint32_t nt_pad, uint32_t* slab, uint32_t* slices, uint32_t desc_off, uint32_t n, uint32_t pass, uint32_t mode) {
+    hipLaunchKernelGGL((gs::ls_pass_kernel<KT, GATHER, COUNT>), dim3(grid), dim3(gs::LS_THREADS), 0, s, in, out, runs, eprefix, stab, nt_pad, slab, slices,
+                       desc_off, n, pass, mode);
+}
+#ifdef GS_MINIMAL
+const LsFirstLauncher g_ls_first[3] = {launch_ls_first<0>, nullptr, nullptr};
+const LsPassLauncher g_ls_pass[3][3] = {{launch_ls_pass<0, true, true>, nullptr, nullptr}, {launch_ls_pass<0, false, true>, nullptr, nullptr}, {launch_ls_pass<0, false, false>, nullptr, nullptr}};
+#else
+const LsFirstLauncher g_ls_first[3] = {launch_ls_first<0>, launch_ls_first<1>, launch_ls_first<2>};
+// [gather / middle / last][key type]
+const LsPassLauncher g_ls_pass[3][3] = {{launch_ls_pass<0, true, true>, launch_ls_pass<1, true, true>, launch_ls_pass<2, true, true>},
+                                        {launch_ls_pass<0, false, true>, launch_ls_pass<1, false, true>, launch_ls_pass<2, false, true>},
+                                        {launch_ls_pass<0, false, false>, launch_ls_pass<1, false, false>, launch_ls_pass<2, false, false>}};
+#endif
+// row stride of R and E: whole 16-byte words and not a power of two (the 256 rows are walked in lockstep by the transpose, the run
+// scan and the 16 chains of the gather pass; a precaution — 16 384-word rows measured the same, profiles/r04_ls_rocprof_stride.txt)
+inline uint32_t ls_nt_pad_for(uint32_t max_keys) { return ((div_up(max_keys, gs::LS_TILE) + 15u) & ~15u) + 272u; }
+// tables of the local-sort plan, words: R[256][nt_pad] | the first kernel's rows [nt_pad][256] | E[256][nt_pad] | S
+inline size_t ls_table_words(uint32_t max_keys) { const size_t p = ls_nt_pad_for(max_keys); return 3 * (size_t)gs::RADIX * p + gs::ls_stab_words((uint32_t)p); }
+
 }  // namespace
 
 struct gs_onesweep {
@@ -187,6 +220,11 @@ struct gs_onesweep {
     // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
     uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
+    // local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys from ls_min_keys up
+    int ls_plan;           // 1 = the local-sort plan for eligible sorts (gs_onesweep_set_plan), 0 = never (default)
+    uint32_t ls_min_keys;
+    uint32_t* ls_runs;     // run table of the first kernel: [256][ls_nt_pad] words
+    uint32_t ls_nt_pad;
     bool exp_keep_desc;  // experiment builds (GS_EXP & 1024): the histogram kernel leaves the descriptor rows alone
 };
 
@@ -427,6 +465,48 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         return GS_OK;
     }
 #endif
+    // Local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys on the default routing, LDS-atomic ranking.  Four launches:
+    // the first kernel sorts every tile locally by digit 0 (keys -> alt) and counts what the gather pass needs; gather pass
+    // (alt -> keys), two plain passes (keys -> alt -> keys).  No histogram sweep, no Scan launch: 32 bytes per key.
+    if (h->ls_plan && h->ls_runs && vb == 0 && !is_key64(kt) && h->rank_mode == 1 && h->shape_auto && h->skip_passes && n >= h->ls_min_keys &&
+        g_ls_first[kt] != nullptr) {
+        const uint32_t nt = div_up(n, gs::LS_TILE);
+        const uint32_t rows1 = gs::ls_gather_rows(nt), rows23 = gs::ls_linear_rows(nt);
+        const uint32_t d1 = SLAB_DESC, d2 = d1 + rows1 * gs::RADIX, d3 = d2 + rows23 * gs::RADIX;
+        const size_t zero_end = (size_t)d3 + (size_t)rows23 * gs::RADIX;
+        if (zero_end > h->slab_words) return GS_ERR_SIZE;
+        h->msd_keys = nullptr;
+        const uint32_t grid = pos_grid();
+        if ((size_t)grid * gs::LS_SLICE_WORDS > (size_t)hist_blocks_cap(h->max_keys) * gs::HIST_TABLE_WORDS) return GS_ERR_SIZE;  // (cannot happen: 2 x CUs slices of 18 KiB in CUs x 128 KiB)
+        uint32_t* slices = h->partials;  // the workgroups' tables (the GlobalHistogram kernel's slices are not in use in this plan)
+        const uint32_t desc_bit = order == GS_ORDER_DESCENDING ? 1u : 0u;
+        uint32_t* ka = static_cast<uint32_t*>(d_keys);
+        uint32_t* kb = static_cast<uint32_t*>(d_alt_keys);
+        if (h->profiling)
+            for (int e = 0; e <= 3; ++e) GS_HIP(hipEventRecord(h->ev[e], s));  // (no clear, no histogram, no scan launch: slots 0..2 stay 0)
+        uint32_t* runs_t = h->ls_runs + (size_t)gs::RADIX * h->ls_nt_pad;  // the first kernel's rows [tile][256]; transposed into ls_runs
+        uint32_t* eprefix = runs_t + (size_t)gs::RADIX * h->ls_nt_pad;
+        uint32_t* stab = eprefix + (size_t)gs::RADIX * h->ls_nt_pad;
+        static const uint32_t ls_exp = getenv("GPUSORT_LS_EXP") ? (uint32_t)strtoul(getenv("GPUSORT_LS_EXP"), nullptr, 0) : 0u;  // tuning bits
+        g_ls_first[kt](s, grid, ka, kb, runs_t, slices, h->slab, zero_end, n, 2u | ls_exp);
+        const uint32_t tblocks = div_up(nt, 64u);
+        hipLaunchKernelGGL(gs::ls_plan_kernel, dim3(tblocks + gs::LS_SLICE_WORDS / 64u), dim3(gs::LS_RED_THREADS), 0, s, runs_t, h->ls_runs, nt, h->ls_nt_pad, tblocks,
+                           slices, grid, h->slab, 2u);
+        hipLaunchKernelGGL(gs::ls_runscan_kernel, dim3(gs::RADIX), dim3(1024), 0, s, h->ls_runs, eprefix, stab, nt, h->ls_nt_pad, h->slab);
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[4], s));
+        g_ls_pass[0][kt](s, grid, kb, ka, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d1, n, 1u, desc_bit | (ls_exp & 0x10000u));
+        hipLaunchKernelGGL(gs::ls_reduce_kernel, dim3(gs::NCH * gs::RADIX / 64u), dim3(gs::LS_RED_THREADS), 0, s, slices, grid, h->slab + gs::SLAB_HSUB + 2u * gs::HSUB_STRIDE);
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));
+        g_ls_pass[1][kt](s, grid, ka, kb, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d2, n, 2u, desc_bit | (ls_exp & 0x10000u));
+        hipLaunchKernelGGL(gs::ls_reduce_kernel, dim3(gs::NCH * gs::RADIX / 64u), dim3(gs::LS_RED_THREADS), 0, s, slices, grid, h->slab + gs::SLAB_HSUB + 3u * gs::HSUB_STRIDE);
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[6], s));
+        g_ls_pass[2][kt](s, grid, kb, ka, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d3, n, 3u, desc_bit | (ls_exp & 0x10000u));
+        if (h->profiling) GS_HIP(hipEventRecord(h->ev[7], s));
+        GS_HIP(hipGetLastError());
+        h->last_tile = 0;     // (gs_debug_check_state: the plan keeps its own state)
+        h->profile_pending = h->profiling != 0;
+        return GS_OK;
+    }
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
     // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
     const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 &&
@@ -555,7 +635,8 @@ const char* gs_status_string(gs_status s) {
 int gs_last_hip_error(void) { return g_last_hip_error; }
 
 size_t gs_onesweep_temp_bytes(uint32_t max_keys) {
-    return (slab_words_for(max_keys) + (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS) * sizeof(uint32_t);
+    return (slab_words_for(max_keys) + (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS +
+            (max_keys > (1u << 25) ? ls_table_words(max_keys) : 0)) * sizeof(uint32_t);
 }
 
 uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes) {
@@ -608,6 +689,10 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->msd_keys = nullptr;
     h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
     h->hist_dirty = false;
+    h->ls_plan = 0;  // opt-in (gs_onesweep_set_plan) until it beats the GlobalHistogram / Scan / 4-pass pipeline on uniform keys
+    h->ls_min_keys = (1u << 25) + 1u;  // (below: the 8192-key tile and the two-launch routes)
+    h->ls_runs = nullptr;
+    h->ls_nt_pad = ls_nt_pad_for(max_keys);
     h->exp_keep_desc = false;
     h->msd_n = h->msd_grid = 0;
     h->msd_kt = GS_KEY_UINT32;
@@ -626,6 +711,8 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&h->partials, (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess && mode == GS_MODE_KEYS_ONLY && max_keys >= h->ls_min_keys)  // the run table of the local-sort plan (16 MiB at 2^28 keys)
+        e = hipMalloc(&h->ls_runs, ls_table_words(max_keys) * sizeof(uint32_t));  // run table, its prefix, tile -> run table (16 + 16 + 16 MiB at 2^28 keys)
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
     if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_DESC * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
@@ -633,6 +720,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
         g_last_hip_error = (int)e;
         if (h->slab) (void)hipFree(h->slab);
         if (h->partials) (void)hipFree(h->partials);
+        if (h->ls_runs) (void)hipFree(h->ls_runs);
         delete h;
         return GS_ERR_HIP;
     }
@@ -647,7 +735,26 @@ gs_status gs_onesweep_destroy(gs_onesweep* h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->slab) (void)hipFree(h->slab);
     if (h->partials) (void)hipFree(h->partials);
+    if (h->ls_runs) (void)hipFree(h->ls_runs);
     delete h;
+    return GS_OK;
+}
+
+gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count, uint32_t* h_out, void* stream) {
+    // bit 31 of first_word: the workgroups' table slices (hist partials) instead of the slab
+    const bool part = (first_word >> 31) != 0u;
+    first_word &= 0x7fffffffu;
+    const size_t limit = part ? (size_t)hist_blocks_cap(h ? h->max_keys : 1u) * gs::HIST_TABLE_WORDS : (h ? h->slab_words : 0);
+    if (!h || !h_out || (size_t)first_word + count > limit) return GS_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GS_HIP(hipMemcpyAsync(h_out, (part ? h->partials : h->slab) + first_word, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    return GS_OK;
+}
+
+gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort) {
+    if (!h || local_sort < 0 || local_sort > 1) return GS_ERR_ARG;
+    h->ls_plan = local_sort;
     return GS_OK;
 }
 

@@ -163,8 +163,12 @@ constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // claim / flag words, two count tables of MID_MAX_TILES rows
 constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
 constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
-constexpr uint32_t SLAB_DESC = SLAB_MID + SLAB_MID_WORDS;
-static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
+// LS: what the local-sort plan (ls_kernels.hpp) keeps beside CNEXT: digit-0 totals, OR / AND of the keys, its first kernel's
+// arrival counter, the plan flags and the gather pass's unit geometry
+constexpr uint32_t SLAB_LS = SLAB_MID + SLAB_MID_WORDS;
+constexpr uint32_t SLAB_LS_WORDS = 1024;
+constexpr uint32_t SLAB_DESC = SLAB_LS + SLAB_LS_WORDS;
+static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_LS % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif

@@ -146,6 +146,14 @@ gs_status gs_onesweep_set_mid_path(gs_onesweep* h, int on);
  * four passes).  Results are identical either way; 0 runs all four passes.  Default 1;
  * env GPUSORT_SKIP_PASSES=0/1 sets it at create. */
 gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
+/* Plan of large keys-only sorts of 32-bit keys (n > 2^25, library-picked shape, rank mode 1).  1: the LOCAL-SORT plan —
+ * the reference's GlobalHistogram + Scan + first DigitBinningPass (GPUSortingCUDA/Sort/OneSweep.cu:44-162 and the first of
+ * :164-344) become ONE kernel that sorts every 16 384-key tile locally by digit 0 and writes it back in place (sequential
+ * stores, no look-back) with a run table; the second pass gathers the runs in (digit, tile) order — which is the first pass's
+ * stable output order — and every pass counts the next pass's histogram while it scatters: 32 bytes of HBM traffic per key
+ * instead of 36.  0 (default): the GlobalHistogram / Scan / 4 x DigitBinningPass pipeline.  The result is bit-identical either
+ * way; profiles/r04_ls_plan_status.txt holds what each kernel of the plan costs today. */
+gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
@@ -164,6 +172,8 @@ gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream)
 /* Test hook: overwrite the device status word gs_onesweep_check() reads (e.g. GS_ERR_TIMEOUT) — every sort must reset it
  * itself, whatever route it takes.  Synchronous. */
 gs_status gs_debug_poke_status(gs_onesweep* h, uint32_t word, void* stream);
+/* Test / tuning hook: copies `count` words of the handle's state slab, from word `first_word`, to the host.  Synchronous. */
+gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count, uint32_t* h_out, void* stream);
 
 /* ---- structural entry points (parity tests, MSD split) --------------------
  * GlobalHistogram + Scan only (GPUSortingCUDA/Sort/OneSweep.cu:44-162): writes
