@@ -625,22 +625,27 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
 #else
     auto stamp = [](int) {};
 #endif
-    // -------------------------------------------------------------------------------------------------------------------
-    // The persistent loop is software-pipelined by one tile: while a tile waits in its look-back and scatters, the NEXT tile is
-    // already claimed and what it needs from memory is on its way — LINEAR: its keys (the key registers are dead once the stage is
-    // written); GATHER: its two S words, then its E and R words (two registers per thread; the gather loads themselves need the
-    // list in LDS and follow the scatter).  At two workgroups per CU the per-tile chain of dependent round trips (ticket, tables,
-    // keys) is otherwise exposed in full (profiles/r04_ls_pass_phase_clocks.txt).
-    // -------------------------------------------------------------------------------------------------------------------
+    // (Measured and not kept, profiles/r04_ls_plan_status.txt: the loop software-pipelined by one tile — the next tile's ticket drawn at
+    //  the top of a tile, its table words / keys requested while the tile waits in its look-back.  A tile claimed a tile time before
+    //  it publishes its counts stalls the look-back of every successor (0.47 -> 0.55 ms per plain pass), and the 32 prefetched key
+    //  registers spill, each scratch reload draining vmcnt, i.e. waiting for the prefetch itself.)
     uint32_t unit_chain = 0xffffffffu;  // GATHER: the chain whose digit tables s_unit holds
-    struct TileGeo {
-        uint32_t chain, tile;
-        uint32_t tile_base, vlo, vhi;        // LINEAR
-        uint32_t gd, gv0;                     // GATHER: digit, virtual start; vhi = keys
-    };
-    // claim by ticket `t` of chain `c` (drawn by the caller), or steal; returns false when every chain is used up.  Uniform; barriers inside.
-    auto resolve = [&](uint32_t c, uint32_t t, TileGeo& g) -> bool {
-        if (GS_UNLIKELY(t >= uni(s_ct[c]))) {
+#pragma unroll 1
+    for (;;) {  // one tile after the other until every chain is claimed
+        __syncthreads();
+        // ---- claim: the ticket counter of chain blockIdx % 16 (one XCD's L2 sees a chain's neighbouring tiles); when that chain
+        // is used up, wave 0 looks at all chains in one round trip ----
+        uint32_t chain = blockIdx.x & (NCH - 1u);
+        if (tid == 0) {
+            s_misc[2] = 0u;  // set when the look-back gives up
+            s_misc[8] = 0u;  // row a stuck look-back asks the workgroup to recount
+            s_misc[1] = atomicAdd(&counters[chain * COUNTER_STRIDE], 1u);
+        }
+        if (tid == 64) s_misc[3] = ld_agent(status);
+        __syncthreads();
+        if (uni(s_misc[3]) != STATUS_OK) break;  // an earlier pass gave up: its output is incomplete
+        uint32_t tile = uni(s_misc[1]);
+        if (GS_UNLIKELY(tile >= uni(s_ct[chain]))) {
             __syncthreads();
             if (wave == 0) {
                 uint32_t tiles_x = 0;
@@ -652,136 +657,85 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                 unsigned long long m = __builtin_amdgcn_ballot_w64(open);
                 uint32_t got_x = 0, got_t = 0xffffffffu;
                 while (m) {  // wave-uniform: the open chains one by one, starting behind our own
-                    const unsigned long long above = m & ~((2ull << c) - 1ull);
+                    const unsigned long long above = m & ~((2ull << chain) - 1ull);
                     const uint32_t x = (uint32_t)__builtin_ctzll(above ? above : m);
-                    uint32_t tt = 0;
-                    if (lane == 0) tt = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
-                    tt = __builtin_amdgcn_readfirstlane(tt);
-                    if (tt < (uint32_t)__builtin_amdgcn_readlane((int)tiles_x, (int)x)) { got_x = x; got_t = tt; break; }
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (t < (uint32_t)__builtin_amdgcn_readlane((int)tiles_x, (int)x)) { got_x = x; got_t = t; break; }
                     m &= ~(1ull << x);
                 }
-                if (lane == 0) { s_misc[12] = got_x; s_misc[13] = got_t; }
+                if (lane == 0) { s_misc[0] = got_x; s_misc[1] = got_t; }
             }
             __syncthreads();
-            c = uni(s_misc[12]);
-            t = uni(s_misc[13]);
-            if (t == 0xffffffffu) return false;
+            chain = uni(s_misc[0]);
+            tile = uni(s_misc[1]);
+            if (tile == 0xffffffffu) break;  // every chain is fully claimed
         }
-        g.chain = c;
-        g.tile = t;
-        if constexpr (!GATHER) {
-            const uint32_t seg_start = uni(s_cstart[c]), seg_end = uni(s_cend[c]);
-            g.tile_base = (seg_start & ~63u) + t * LS_TILE;
-            const uint32_t lo = g.tile_base > seg_start ? g.tile_base : seg_start;
-            const uint32_t hi = (seg_end - g.tile_base < LS_TILE) ? seg_end : g.tile_base + LS_TILE;
-            g.vlo = lo - g.tile_base;
-            g.vhi = hi - g.tile_base;
-        }
-        return true;
-    };
-    // GATHER: the digit of tile g.tile of chain g.chain and its S index; requests the two S words (not waited for)
-    uint32_t sw0 = 0, sw1 = 0;  // S words of the NEXT tile (vector registers until used)
-    auto gather_geo = [&](TileGeo& g) {
-        if (GS_UNLIKELY(g.chain != unit_chain)) {  // (uniform) another chain's tickets: its digit tables
-            __syncthreads();
-            if (tid < 3 * NCH) s_unit[tid] = ls[(tid < NCH ? LS_SB : tid < 2 * NCH ? LS_UU0 - NCH : LS_TOT0 - 2 * NCH) + g.chain * NCH + tid];
-            __syncthreads();
-            unit_chain = g.chain;
-        }
-        uint32_t i = 0;
-        while (i + 1u < NCH && uni(s_unit[NCH + i + 1u]) <= g.tile) ++i;
-        g.gd = g.chain * NCH + i;
-        const uint32_t j = g.tile - uni(s_unit[NCH + i]), sidx = uni(s_unit[i]) + j, tot = uni(s_unit[2 * NCH + i]);
-        g.gv0 = j * LS_TILE;
-        g.vlo = 0;
-        g.vhi = tot - g.gv0 < LS_TILE ? tot - g.gv0 : LS_TILE;
-        sw0 = stab[sidx];
-        sw1 = stab[sidx + 1u];
-    };
-    uint32_t key[LS_KPT];          // LINEAR: the NEXT tile's keys as they lie in memory, from the moment they are requested
-    uint32_t ew = 0, rw = 0;       // GATHER: E and R word of run ge0 + tid of the next tile
-    uint32_t ge0 = 0, ge1 = 0;
-    auto linear_request = [&](const TileGeo& g) {
-        uint32_t p0 = wave * (64u * LS_KPT) + lane;
-        asm volatile("" : "+v"(p0));  // (not hoisted out of the loop as 32 registers: see the gather loads)
-        // (the tile's base as a SCALAR pointer: through the struct the compiler takes it for a vector value and builds 32 64-bit addresses)
-        const uint32_t* tin = keys_in + uni(g.tile_base);
-        const uint32_t lo = uni(g.vlo), hi = uni(g.vhi);
-        if (GS_LIKELY(hi - lo == LS_TILE)) {
-#pragma unroll
-            for (int i = 0; i < (int)LS_KPT; ++i) key[i] = __builtin_nontemporal_load(tin + p0 + i * 64u);
-        } else {
-#pragma unroll
-            for (int i = 0; i < (int)LS_KPT; ++i) {
-                const uint32_t p = p0 + i * 64u;
-                key[i] = tin[p < lo ? lo : (p >= hi ? hi - 1u : p)];
-            }
-        }
-    };
-    auto gather_request = [&](const TileGeo& g) {  // (the S words have arrived by now)
-        ge0 = uni(sw0);
-        ge1 = uni(sw1);
-        const uint32_t i = ge0 + tid;
-        const uint32_t ic = i <= ge1 ? i : ge1;
-        const size_t rowoff = (size_t)uni(g.gd) * nt_pad;
-        ew = (eprefix + rowoff)[ic];
-        rw = (runs + rowoff)[ic];
-    };
-
-    TileGeo cur, nxt;
-    bool have = false;
-    {   // the first tile
-        if (tid == 0) s_misc[1] = atomicAdd(&counters[(blockIdx.x & (NCH - 1u)) * COUNTER_STRIDE], 1u);
-        if (tid == 64) s_misc[3] = ld_agent(status);
-        __syncthreads();
-        if (uni(s_misc[3]) == STATUS_OK) have = resolve(blockIdx.x & (NCH - 1u), uni(s_misc[1]), cur);
-        if (have) {
-            if constexpr (GATHER) { gather_geo(cur); gather_request(cur); }
-            else linear_request(cur);
-        }
-    }
-#pragma unroll 1
-    while (have) {
-        __syncthreads();  // the last tile's readers of the stage, the counters and s_misc are through
-        const uint32_t chain = uni(cur.chain), tile = uni(cur.tile);
-        if (tid == 0) {
-            s_misc[2] = 0u;  // set when the look-back gives up
-            s_misc[8] = 0u;  // row a stuck look-back asks the workgroup to recount
-            s_misc[1] = atomicAdd(&counters[(blockIdx.x & (NCH - 1u)) * COUNTER_STRIDE], 1u);  // the NEXT tile's ticket
-        }
-        if (tid == 64) s_misc[3] = ld_agent(status);
-        stamp(0);
+        stamp(0);  // claimed
         uint32_t* cdesc = desc + (size_t)uni(s_crow[chain]) * RADIX;  // row 0 of this chain
         if (GS_UNLIKELY(tile == 0u && tid < RADIX)) {  // the chain's base: the digit's start plus the chains in front
             uint32_t seed = my_dstart;
             for (uint32_t x = 0; x < chain; ++x) seed += cn_in[tid * NCH + x];
             st_agent(&cdesc[tid], (seed << 2) | FLAG_INCLUSIVE);
         }
-        const uint32_t vlo = uni(cur.vlo), vhi = uni(cur.vhi);
-        const uint32_t cnt = vhi - vlo;
-        const bool full = cnt == LS_TILE;
-        stamp(1);
 
+        // ---- geometry of the tile ----
+        // LINEAR: the chain's tile grid starts at its start rounded down to 64 keys (256-byte aligned wave loads); positions
+        // [vlo, vhi) of the tile are its keys.  GATHER: tile j of digit gd, runs [ge0, ge1] of that digit's row, virtual start gv0.
+        uint32_t tile_base = 0, vlo = 0, vhi = 0;
+        uint32_t gd = 0, ge0 = 0, ge1 = 0, gv0 = 0;
+        if constexpr (!GATHER) {
+            const uint32_t seg_start = uni(s_cstart[chain]), seg_end = uni(s_cend[chain]);
+            tile_base = (seg_start & ~63u) + tile * LS_TILE;
+            const uint32_t lo = tile_base > seg_start ? tile_base : seg_start;
+            const uint32_t hi = (seg_end - tile_base < LS_TILE) ? seg_end : tile_base + LS_TILE;
+            vlo = lo - tile_base;
+            vhi = hi - tile_base;
+        } else {
+            if (GS_UNLIKELY(chain != unit_chain)) {  // (uniform) another chain's tickets: its digit tables
+                __syncthreads();
+                if (tid < 3 * NCH) s_unit[tid] = ls[(tid < NCH ? LS_SB : tid < 2 * NCH ? LS_UU0 - NCH : LS_TOT0 - 2 * NCH) + chain * NCH + tid];
+                __syncthreads();
+                unit_chain = chain;
+            }
+            uint32_t i = 0;
+            while (i + 1u < NCH && uni(s_unit[NCH + i + 1u]) <= tile) ++i;
+            gd = chain * NCH + i;
+            const uint32_t j = tile - uni(s_unit[NCH + i]), sidx = uni(s_unit[i]) + j, tot = uni(s_unit[2 * NCH + i]);
+            ge0 = uni(stab[sidx]);
+            ge1 = uni(stab[sidx + 1u]);
+            gv0 = j * LS_TILE;
+            vlo = 0;
+            vhi = tot - gv0 < LS_TILE ? tot - gv0 : LS_TILE;
+        }
+        const uint32_t cnt = uni(vhi - vlo);
+        const bool full = cnt == LS_TILE;
+        stamp(1);  // geometry
+
+        // ---- load ----
+        uint32_t key[LS_KPT];
+        // (opaque per tile: left to itself the compiler hoists all 32 positions p0 + 64 i out of the persistent loop, spills some of
+        //  them, and every scratch reload waits for vmcnt(0) — the key loads then go out one at a time: 59 000 clocks per tile in this
+        //  phase, profiles/r04_ls_pass_phase_clocks.txt)
+        uint32_t p0 = wave * (64u * LS_KPT) + lane;
+        asm volatile("" : "+v"(p0));
         if constexpr (GATHER) {
-            // ---- the run list (in the stage) and the run-start bitmap (in the counters' words), from the E / R words requested a tile ago ----
+            // the run list (in the stage) and the run-start bitmap (in the counters' words)
             uint32_t* s_list = s_stage;
             uint32_t* s_bits = s_whist;
-            const uint32_t gv0 = uni(cur.gv0);
-            const size_t rowoff = (size_t)uni(cur.gd) * nt_pad;
             s_bits[tid] = 0;
             __syncthreads();
             {
+                const uint32_t* erow = eprefix + (size_t)gd * nt_pad;
+                const uint32_t* rrow = runs + (size_t)gd * nt_pad;
                 uint32_t nrun = 0;  // uniform: runs listed so far
-                uint32_t a = ew, w = rw;
 #pragma unroll 1
                 for (uint32_t e = ge0; e <= ge1; e += LS_THREADS) {
                     const uint32_t i = e + tid;
-                    if (e != ge0 && i <= ge1) {  // (tiles of more than 512 runs: sparse digits)
-                        a = (eprefix + rowoff)[i];
-                        w = (runs + rowoff)[i];
-                    }
                     uint32_t f = 0, s0 = 0, src = 0;
                     if (i <= ge1) {
+                        const uint32_t a = erow[i], w = rrow[i];
                         const uint32_t b = a + (w & 0xffffu);                   // the run's virtual range [a, b)
                         const uint32_t lo = a > gv0 ? a : gv0, hi = b < gv0 + cnt ? b : gv0 + cnt;
                         f = hi > lo ? 1u : 0u;
@@ -793,9 +747,9 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                     __syncthreads();
                     uint32_t bf = nrun, totf = 0;
 #pragma unroll
-                    for (uint32_t ww = 0; ww < LS_WAVES; ++ww) {
-                        const uint32_t wf = s_misc[32 + ww];
-                        if (ww < wave) bf += wf;
+                    for (uint32_t w = 0; w < LS_WAVES; ++w) {
+                        const uint32_t wf = s_misc[32 + w];
+                        if (w < wave) bf += wf;
                         totf += wf;
                     }
                     if (f) {
@@ -806,7 +760,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                     __syncthreads();
                 }
             }
-            stamp(2);
+            stamp(2);  // run list
             const unsigned long long* s_bits64 = reinterpret_cast<const unsigned long long*>(s_whist);
             unsigned long long mine = 0;
             if (lane < LS_KPT) mine = s_bits64[wave * LS_KPT + lane];  // lane i: the run-start bits of the wave's item i
@@ -814,14 +768,10 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
             if (lane == 0) s_misc[40 + wave] = pc;
             __syncthreads();
             uint32_t before = 0;  // uniform: runs that start in front of this wave's 2048 positions
-            for (uint32_t ww = 0; ww < wave; ++ww) before += s_misc[40 + ww];
+            for (uint32_t w = 0; w < wave; ++w) before += s_misc[40 + w];
             before = uni(before);
             const uint32_t mlo_v = (uint32_t)mine, mhi_v = (uint32_t)(mine >> 32);
             const uint32_t last = cnt ? cnt - 1u : 0u;
-            // (opaque per tile: left to itself the compiler hoists all 32 positions p0 + 64 i out of the persistent loop, spills some of
-            //  them, and every scratch reload waits for vmcnt(0) — the key loads then go out one at a time: 59 000 clocks per tile)
-            uint32_t p0 = wave * (64u * LS_KPT) + lane;
-            asm volatile("" : "+v"(p0));
             if (GS_LIKELY(cnt != 0u)) {
 #pragma unroll
                 for (int i = 0; i < (int)LS_KPT; ++i) {
@@ -830,51 +780,48 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                     const uint32_t self = (uint32_t)((((unsigned long long)mhi << 32) | mlo) >> lane) & 1u;
                     const uint32_t r = before + below + self - 1u;  // (position 0 of a non-empty tile starts a run)
                     before += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-                    key[i] = s_list[r];  // (all 32 list reads in flight, then all 32 key loads)
+                    key[i] = s_list[r];  // (all 32 list reads in flight, then all 32 key loads: one LDS round trip, not 32)
                 }
 #pragma unroll
                 for (int i = 0; i < (int)LS_KPT; ++i) {
                     const uint32_t p = p0 + i * 64u;
-                    key[i] = keys_in[key[i] + (p < cnt ? p : last)];  // (positions behind a partial tile read its last key again)
+                    // (positions behind a partial tile read its last key again)
+                    key[i] = to_bits<KT>(keys_in[key[i] + (p < cnt ? p : last)]);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < (int)LS_KPT; ++i) key[i] = 0xffffffffu;
             }
             __syncthreads();  // the list and the bitmap are read: stage and counters may be reused
+        } else if (GS_LIKELY(full)) {
+#pragma unroll
+            for (int i = 0; i < (int)LS_KPT; ++i) key[i] = to_bits<KT>(__builtin_nontemporal_load(keys_in + tile_base + p0 + i * 64u));
+        } else {
+#pragma unroll
+            for (int i = 0; i < (int)LS_KPT; ++i) {
+                const uint32_t p = p0 + i * 64u;
+                const uint32_t pc = p < vlo ? vlo : (p >= vhi ? vhi - 1u : p);
+                key[i] = to_bits<KT>(keys_in[tile_base + pc]);
+            }
         }
-        stamp(3);
+        stamp(3);  // loads issued (GATHER: and the list is read)
 
         s_whist[tid] = 0;
         s_whist[tid + LS_THREADS] = 0;
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < (int)LS_KPT; ++i) key[i] = to_bits<KT>(key[i]);
         uint32_t offp[LS_KPT / 2];
-        __builtin_amdgcn_sched_barrier(0);
         ls_rank<COUNT>(T, key, offp, shift, full, vlo, vhi, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(4);
+        stamp(4);  // waited for the keys, ranked
         __syncthreads();
         uint32_t c0, c1, dpre0, dpre1;
         ls_digit_scan(T, tid, c0, c1, dpre0, dpre1);
-        stamp(5);
+        stamp(5);  // barrier + digit scan
         if (tid < RADIX / 2 && !GS_FAULT_TILE(chain, tile))  // publish the tile's counts (the pair in one 8-byte store)
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(&cdesc[(size_t)(tile + 1u) * RADIX + 2u * tid]),
                                ((unsigned long long)((c1 << 2) | FLAG_REDUCTION) << 32) | ((c0 << 2) | FLAG_REDUCTION),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ls_stage(T, key, offp, shift, full, vlo, vhi, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(6);
-
-        // ---- the next tile: claimed by the ticket drawn at the top.  Loads return in order: what is requested in front of the look-back
-        // delays its first descriptor read, and with it every successor's — so only the gather pass's two S words go out here, the
-        // keys (LINEAR) and the E / R words (GATHER) behind the look-back ----
-        bool have_next = uni(s_misc[3]) == STATUS_OK;  // (an earlier pass gave up: its output is incomplete — stop)
-        if (have_next) have_next = resolve(blockIdx.x & (NCH - 1u), uni(s_misc[1]), nxt);
-        if constexpr (GATHER) {
-            if (have_next) gather_geo(nxt);   // requests its S words
-        }
+        stamp(6);  // staged
 
         // ---- decoupled look-back inside the chain: threads < 128 walk for two digits each ----
         uint32_t prev0 = 0, prev1 = 0;  // keys of digits 2 tid, 2 tid + 1 in front of this tile in the pass's output
@@ -959,16 +906,15 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                         const uint32_t fhi = (seg_end - fbase < LS_TILE) ? seg_end : fbase + LS_TILE;
                         for (uint32_t idx = flo + tid; idx < fhi; idx += LS_THREADS)
                             atomicAdd(&s_gbase[(to_bits<KT>(keys_in[idx]) >> shift) & 255u], 1u);
-                    } else {  // tile ft of the chain (its digit tables straight from memory: s_unit may already hold the next tile's chain)
-                        const uint32_t* uu0 = ls + LS_UU0 + chain * NCH;
+                    } else {  // tile ft of the chain: one wave per run
                         uint32_t i = 0;
-                        while (i + 1u < NCH && uni(uu0[i + 1u]) <= ft) ++i;
-                        const uint32_t fd = chain * NCH + i, fj = ft - uni(uu0[i]), fs = uni(ls[LS_SB + fd]) + fj, ftot = uni(ls[LS_TOT0 + fd]);
+                        while (i + 1u < NCH && uni(s_unit[NCH + i + 1u]) <= ft) ++i;
+                        const uint32_t fd = chain * NCH + i, fj = ft - uni(s_unit[NCH + i]), fs = uni(s_unit[i]) + fj, ftot = uni(s_unit[2 * NCH + i]);
                         const uint32_t f0 = uni(stab[fs]), f1 = uni(stab[fs + 1u]), fv0 = fj * LS_TILE;
                         const uint32_t fv1 = ftot - fv0 < LS_TILE ? ftot : fv0 + LS_TILE;
                         const uint32_t* erow = eprefix + (size_t)fd * nt_pad;
                         const uint32_t* rrow = runs + (size_t)fd * nt_pad;
-                        for (uint32_t e = f0 + wave; e <= f1; e += LS_WAVES) {  // one wave per run
+                        for (uint32_t e = f0 + wave; e <= f1; e += LS_WAVES) {
                             const uint32_t a = uni(erow[e]), w = uni(rrow[e]);
                             const uint32_t b = a + (w & 0xffffu), lo = a > fv0 ? a : fv0, hi = b < fv1 ? b : fv1;
                             const uint32_t src = e * LS_TILE + (w >> 16) + (lo - a);
@@ -996,12 +942,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
             }
         }
         if (uni(s_misc[2]) != 0u) break;  // timeout or poisoned predecessor: write nothing
-        stamp(7);
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_next) {
-            if constexpr (GATHER) gather_request(nxt);  // its S words are here: request its E and R words
-            else linear_request(nxt);                   // its keys fly while this tile is scattered
-        }
+        stamp(7);  // look-back
         if (tid < RADIX / 2) {  // stage slot i of digit d goes to s_gbase[d] + i
             s_gbase[2 * tid] = prev0 - dpre0;
             s_gbase[2 * tid + 1] = prev1 - dpre1;
@@ -1011,40 +952,34 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
         const int flush = __syncthreads_or(near ? 1 : 0);
         stamp(8);
 
-        // ---- scatter (rounds of eight stage slots per thread: LINEAR keeps the next tile's 32 keys in registers meanwhile) ----
+        // ---- scatter: all stage reads first, then the base look-ups, then the stores ----
+        if (GS_LIKELY(full)) {
+            uint32_t kb[LS_KPT];
 #pragma unroll
-        for (int j0 = 0; j0 < (int)LS_KPT; j0 += 8) {
-            __builtin_amdgcn_sched_barrier(0);  // (one round's reads and stores at a time: the scheduler would hoist all 32 stage reads)
-            if (GS_LIKELY(full)) {
-                uint32_t kb[8];
+            for (int j = 0; j < (int)LS_KPT; ++j) kb[j] = s_stage[tid + j * LS_THREADS];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) kb[j] = s_stage[tid + (j0 + j) * LS_THREADS];
+            for (int j = 0; j < (int)LS_KPT; ++j) {
+                const uint32_t o = s_gbase[(kb[j] >> shift) & 255u] + tid + j * LS_THREADS;
+                keys_out[(o ^ rev_xor) + rev_add] = from_bits<KT>(kb[j]);
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t o = s_gbase[(kb[j] >> shift) & 255u] + tid + (j0 + j) * LS_THREADS;
-                    keys_out[(o ^ rev_xor) + rev_add] = from_bits<KT>(kb[j]);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t i = tid + (j0 + j) * LS_THREADS;
-                    if (i < cnt) {
-                        const uint32_t kb = s_stage[i];
-                        const uint32_t o = s_gbase[(kb >> shift) & 255u] + i;
-                        keys_out[(o ^ rev_xor) + rev_add] = from_bits<KT>(kb);
-                    }
+            for (int j = 0; j < (int)LS_KPT; ++j) {
+                const uint32_t i = tid + j * LS_THREADS;
+                if (i < cnt) {
+                    const uint32_t kb = s_stage[i];
+                    const uint32_t o = s_gbase[(kb >> shift) & 255u] + i;
+                    keys_out[(o ^ rev_xor) + rev_add] = from_bits<KT>(kb);
                 }
             }
         }
         if constexpr (COUNT) {
             if (GS_UNLIKELY(flush)) ls_tab_flush(s_tab, slice, tid);
         }
-        stamp(9);
+        stamp(9);  // scattered
 #if GS_LS_CLOCK
         if (clk_on) ++s_misc[58];
 #endif
-        cur = nxt;
-        have = have_next;
     }
 #if GS_LS_CLOCK
     if (clk_on) {
