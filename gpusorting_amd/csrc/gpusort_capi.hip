@@ -468,8 +468,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // Local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys on the default routing, LDS-atomic ranking.  Four launches:
     // the first kernel sorts every tile locally by digit 0 (keys -> alt) and counts what the gather pass needs; gather pass
     // (alt -> keys), two plain passes (keys -> alt -> keys).  No histogram sweep, no Scan launch: 32 bytes per key.
-    if (h->ls_plan && h->ls_runs && vb == 0 && !is_key64(kt) && h->rank_mode == 1 && h->shape_auto && h->skip_passes && n >= h->ls_min_keys &&
-        g_ls_first[kt] != nullptr) {
+    if (h->ls_plan && h->ls_runs && vb == 0 && !is_key64(kt) && h->rank_mode == 1 && h->shape_auto && h->skip_passes &&
+        (n >= h->ls_min_keys || h->ls_plan == 2) && g_ls_first[kt] != nullptr) {
         const uint32_t nt = div_up(n, gs::LS_TILE);
         const uint32_t rows1 = gs::ls_gather_rows(nt), rows23 = gs::ls_linear_rows(nt);
         const uint32_t d1 = SLAB_DESC, d2 = d1 + rows1 * gs::RADIX, d3 = d2 + rows23 * gs::RADIX;
@@ -753,7 +753,8 @@ gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count
 }
 
 gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort) {
-    if (!h || local_sort < 0 || local_sort > 1) return GS_ERR_ARG;
+    if (!h || local_sort < 0 || local_sort > 2) return GS_ERR_ARG;
+    if (local_sort != 0 && !h->ls_runs) return GS_ERR_MODE;  // (the handle was created without the plan's tables: pairs, or max_keys <= 2^25)
     h->ls_plan = local_sort;
     return GS_OK;
 }

@@ -112,6 +112,34 @@ __device__ __forceinline__ void ls_rank(const LsTile& T, const uint32_t (&key)[L
     }
 }
 
+// adds the tile's valid keys to the next-digit joint table (a loop of its own behind the staging: inside the ranking loop the two
+// atomics per key kept 48 registers of keys and ranks live next to each other's temporaries, and the gather pass spilled ranks)
+__device__ __forceinline__ void ls_count(const LsTile& T, const uint32_t (&key)[LS_KPT], uint32_t shift, bool full, uint32_t vlo, uint32_t vhi,
+                                         uint32_t wave, uint32_t lane) {
+    uint32_t p0 = wave * (64u * LS_KPT) + lane;
+    asm volatile("" : "+v"(p0));
+    {
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave * (64u * LS_KPT)));
+        full = full || (w0 >= (uint32_t)__builtin_amdgcn_readfirstlane((int)vlo) && w0 + 64u * LS_KPT <= (uint32_t)__builtin_amdgcn_readfirstlane((int)vhi));
+    }
+    if (GS_LIKELY(full)) {
+#pragma unroll
+        for (int i = 0; i < (int)LS_KPT; ++i) {
+            const uint32_t b = (key[i] >> (shift + 4u)) & 0xfffu;  // (next digit << 4) | group of this digit
+            __hip_atomic_fetch_add(&T.s_tab[b >> 1], 1u << ((b & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < (int)LS_KPT; ++i) {
+            const uint32_t p = p0 + i * 64u;
+            if (p >= vlo && p < vhi) {
+                const uint32_t b = (key[i] >> (shift + 4u)) & 0xfffu;
+                __hip_atomic_fetch_add(&T.s_tab[b >> 1], 1u << ((b & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
 // After the ranking barrier: threads k < 128 own the digit pair (2k, 2k + 1).  Turns the per-wave counters into (exclusive prefix
 // over the waves + tile-local start of the digit's run), returns the pair's counts and run starts.
 // Contains two barriers; every thread of the workgroup must call it.
@@ -810,7 +838,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
         s_whist[tid + LS_THREADS] = 0;
         __syncthreads();
         uint32_t offp[LS_KPT / 2];
-        ls_rank<COUNT>(T, key, offp, shift, full, vlo, vhi, wave, lane);
+        ls_rank<false>(T, key, offp, shift, full, vlo, vhi, wave, lane);
         stamp(4);  // waited for the keys, ranked
         __syncthreads();
         uint32_t c0, c1, dpre0, dpre1;
@@ -821,7 +849,8 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                                ((unsigned long long)((c1 << 2) | FLAG_REDUCTION) << 32) | ((c0 << 2) | FLAG_REDUCTION),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ls_stage(T, key, offp, shift, full, vlo, vhi, wave, lane);
-        stamp(6);  // staged
+        if constexpr (COUNT) ls_count(T, key, shift, full, vlo, vhi, wave, lane);
+        stamp(6);  // staged (and counted)
 
         // ---- decoupled look-back inside the chain: threads < 128 walk for two digits each ----
         uint32_t prev0 = 0, prev1 = 0;  // keys of digits 2 tid, 2 tid + 1 in front of this tile in the pass's output

@@ -164,9 +164,10 @@ class OneSweep:
         """Identity passes (one digit value for all keys) are dropped in pairs on the device (default on)."""
         check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")
 
-    def set_plan(self, local_sort: bool) -> None:
-        """Large keys-only sorts of 32-bit keys: the local-sort plan (ls_kernels.hpp) or the GlobalHistogram / Scan / 4-pass pipeline (default)."""
-        check(self._lib.gs_onesweep_set_plan(self._h, 1 if local_sort else 0), "gs_onesweep_set_plan")
+    def set_plan(self, local_sort) -> None:
+        """Large keys-only sorts of 32-bit keys: 1 / True the local-sort plan (ls_kernels.hpp), 0 / False the GlobalHistogram / Scan /
+        4-pass pipeline (default), 2 the local-sort plan at every size of the general path (tests)."""
+        check(self._lib.gs_onesweep_set_plan(self._h, int(local_sort)), "gs_onesweep_set_plan")
 
     @property
     def key_bytes(self) -> int:

@@ -151,8 +151,10 @@ gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
  * :164-344) become ONE kernel that sorts every 16 384-key tile locally by digit 0 and writes it back in place (sequential
  * stores, no look-back) with a run table; the second pass gathers the runs in (digit, tile) order — which is the first pass's
  * stable output order — and every pass counts the next pass's histogram while it scatters: 32 bytes of HBM traffic per key
- * instead of 36.  0 (default): the GlobalHistogram / Scan / 4 x DigitBinningPass pipeline.  The result is bit-identical either
- * way; profiles/r04_ls_plan_status.txt holds what each kernel of the plan costs today. */
+ * instead of 36.  0 (default): the GlobalHistogram / Scan / 4 x DigitBinningPass pipeline.  2 (tests): the local-sort plan at
+ * EVERY size the general path would take.  The result is bit-identical either way; profiles/r04_ls_plan_status.txt holds what each
+ * kernel of the plan costs today and why it is not the default.  GS_ERR_MODE: the handle has no tables for the plan (pairs, or
+ * max_keys <= 2^25). */
 gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
