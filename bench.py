@@ -265,7 +265,7 @@ def more_block(g, n, log2, steps):
     out["entropy_sweep"] = rows
     out["entropy_sweep_note"] = ("sorts of skewed keys (presets 2-5; keys-only and pairs) run on position chains in every pass (decided on the "
                                  "device: the histogram kernel finds the digit groups uneven); counting passes use 12 288-key tiles")
-    # ---- 64-bit keys: two stable 4-pass rounds over 8-byte elements ----
+    # ---- 64-bit keys: eight passes over 8-byte elements, planned by ONE histogram sweep + Scan ----
     n64 = min(n, 1 << 27)
     k64 = [torch.empty(n64, dtype=torch.int64, device="cuda") for _ in range(3)]
     a64 = torch.empty(n64, dtype=torch.int64, device="cuda")

@@ -320,9 +320,10 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     const uint32_t seg_unit = (tile0 % gs::HIST_CHUNK == 0u) ? tile0 : gs::HIST_CHUNK;
     const uint32_t seg_len0 = div_up(div_up(n, gs::NCH), seg_unit) * seg_unit;
     // no separate clear: the histogram kernel zeroes the scan state while it reads the keys (profile slot 0 stays 0)
-    // The histogram kernel ACCUMULATES into HIST and relies on it being zero between calls (the first pass
-    // launched after the Scan, or the read-back entry points, hand it back zeroed).  A call that failed in
-    // between left it dirty: zero it here, once, instead of double counting silently.
+    // hist_reduce_kernel OVERWRITES the np tables it sums; the tables it does not touch and the HX words (HX_SKEW and the keys'
+    // OR / AND, which the histogram kernel sets with atomics) rely on the HIST region being zero between calls — the first pass
+    // launched after the Scan, or the read-back entry points, hand it back zeroed.  A call that failed in between left it
+    // dirty: zero it here, once.
     if (h->hist_dirty) GS_HIP(zero_hist(h, s));
     // (64-bit keys: passes 4..7 — or the second round's kernels — are charged to slot 6; the events of round 0 stay where they are)
     const bool rec = h->profiling && word == 0;

@@ -443,7 +443,11 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
                 if (local == GS_OK) local = gs_onesweep_digit_pass(h, d_out_keys, c->part_keys, d_out_vals, c->part_vals, n, 3, kt, 0, s);
             }
         }
-        GS_HIP(hipEventRecord(c->ev[1], s));
+        // (from the plan on NOTHING returns before the closing status gather: a rank that left here would strand its peers in
+        //  ncclRecv or in that gather — every error is kept in `local`, the collectives are entered regardless, and the error is
+        //  returned behind them)
+        auto note = [&](gs_status e) { if (local == GS_OK) local = e; };
+        if (hipEventRecord(c->ev[1], s) != hipSuccess) note(GS_ERR_HIP);
         // bucket exchange
         std::vector<uint32_t> sd(W), rd(W);
         uint32_t a = 0, b = 0;
@@ -458,27 +462,26 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         hipStream_t tail = s;  // the stream the closing status gather goes on
         if (vb && c->overlap) {
             // keys on the caller's stream; values on the second stream (and the second communicator) behind the partition pass
-            if (hipEventRecord(c->ev_part, s) != hipSuccess || hipStreamWaitEvent(c->s2, c->ev_part, 0) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
-            if (c->transport.exchange(c->transport.user, 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) { c->failed = 1; return GS_ERR_COMM; }
-            if (c->transport2.exchange(c->transport2.user, 1u, src + 1, dst + 1, eb + 1, send, sd.data(), recv, rd.data(), c->s2) != 0) { c->failed = 1; return GS_ERR_COMM; }
-            if (hipEventRecord(c->ev_vals, c->s2) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
+            if (hipEventRecord(c->ev_part, s) != hipSuccess || hipStreamWaitEvent(c->s2, c->ev_part, 0) != hipSuccess) note(GS_ERR_HIP);
+            if (c->transport.exchange(c->transport.user, 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) note(GS_ERR_COMM);
+            if (c->transport2.exchange(c->transport2.user, 1u, src + 1, dst + 1, eb + 1, send, sd.data(), recv, rd.data(), c->s2) != 0) note(GS_ERR_COMM);
+            if (hipEventRecord(c->ev_vals, c->s2) != hipSuccess) note(GS_ERR_HIP);
             values_ready = c->ev_vals;
             tail = c->s2;
         } else if (c->transport.exchange(c->transport.user, vb ? 2u : 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) {
-            c->failed = 1;
-            return GS_ERR_COMM;
+            note(GS_ERR_COMM);
         }
-        GS_HIP(hipEventRecord(c->ev[2], s));
+        if (hipEventRecord(c->ev[2], s) != hipSuccess) note(GS_ERR_HIP);
         // closing status gather: every rank learns whether some peer carried an error through the exchange
         c->h_status[0] = (uint32_t)local;
         if (hipMemcpyAsync(c->d_status, c->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, tail) != hipSuccess ||
             (vb && c->overlap ? c->transport2 : c->transport).all_gather_u32((vb && c->overlap ? c->transport2 : c->transport).user,
                                                                              c->d_status, c->d_status + 1, 1, tail) != 0) {
-            c->failed = 1;
-            return GS_ERR_COMM;
+            c->failed = 1;  // (the gather itself failed: nothing more this rank can do for its peers)
+            return local != GS_OK ? local : GS_ERR_COMM;
         }
         if (tail != s) {  // the caller's stream must not run ahead of the side stream's last use of the context
-            if (hipEventRecord(c->ev_tail, tail) != hipSuccess) { c->failed = 1; return GS_ERR_HIP; }
+            if (hipEventRecord(c->ev_tail, tail) != hipSuccess) note(GS_ERR_HIP);
         }
         if (local != GS_OK) {  // the peers are served; this rank's own result is not there
             if (tail != s) (void)hipStreamWaitEvent(s, c->ev_tail, 0);
@@ -509,7 +512,9 @@ gs_status gs_mgpu_check(gs_mgpu* c, void* stream) {
     if (c->world > 1 || c->force_exchange)
         for (uint32_t r = 0; r < c->world; ++r)
             if (c->h_status[1 + r] != GS_OK) { c->failed = 1; return GS_ERR_COMM; }  // a peer carried an error through the exchange
-    return gs_onesweep_check(c->sorter, stream);
+    const gs_status st = gs_onesweep_check(c->sorter, stream);
+    if (st == GS_OK) c->failed = 0;  // the last call was clean on every rank: the context has recovered (teardown destroys, not aborts)
+    return st;
 }
 
 gs_status gs_mgpu_debug_fail(gs_mgpu* c, int where) {

@@ -75,6 +75,9 @@ __host__ __device__ constexpr uint32_t mid_tag(uint32_t epoch, uint32_t step) { 
 #define GS_MID_STAMP(i) do { } while (0)
 #define GS_MID_STAMP2(i) do { } while (0)
 #endif
+#ifndef GS_FAULT_MID_SILENT
+#define GS_FAULT_MID_SILENT(block) false  // fault injection: this workgroup of K1 claims its tile and then never publishes anything
+#endif
 #ifndef GS_FAULT_MID_ABSENT
 #define GS_FAULT_MID_ABSENT(block) false  // fault injection: this workgroup of K1 behaves as if it had never been dispatched
 #endif
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     load_tile(blockIdx.x, keys, vals_, false);
     __syncthreads();
     if (uni(s_ctl[0]) == 0u) return;  // somebody adopted the tile while this workgroup was waiting to be dispatched
+    if (GS_FAULT_MID_SILENT(blockIdx.x)) return;  // (fault build: the tile is claimed — nobody can adopt it — and stays silent)
     uint32_t n_owned = 1;        // uniform
     bool own_in_regs = true;     // uniform: the registers still hold the own tile as loaded above
 
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
     // wait until every tile's flag word has reached `tag`.  adopt: a tile nobody has claimed is taken over (its counts are
     // published by this workgroup at once, its scatter follows this workgroup's own).  false = gave up (status word set).
     auto wait_flags = [&](const uint32_t* flags, uint32_t tag, bool adopt, uint32_t shift, uint32_t* table) -> bool {
-        uint32_t spins = 0;  // uniform
+        uint32_t spins = 0, since_adopt = 0;  // uniform: polls without progress (bounded by SPIN_LIMIT in every mode), polls since the last adoption attempt
         if (tid == 0) s_ctl[1] = 0xffffffffu;
         __syncthreads();
         for (;;) {
@@ -257,18 +261,23 @@ __global__ __launch_bounds__(THREADS_) void mid_msd_kernel(uint32_t* keys, uint3
             if (tid == 0) s_ctl[1] = 0xffffffffu;
             __syncthreads();
             spins += 8u;
-            if (adopt && spins >= GS_MID_ADOPT_SPINS) {
-                spins = 0;
+            since_adopt += 8u;
+            if (adopt && since_adopt >= GS_MID_ADOPT_SPINS) {
+                // (the adoption cadence has its own counter: `spins` keeps growing while attempts FAIL — a tile that was claimed but whose
+                //  counts never appear must run into SPIN_LIMIT below like every other wait, not spin for ever)
+                since_adopt = 0;
                 if (tid == 0) s_ctl[0] = atomicMax(&claim[missing], epoch) < epoch ? 1u : 0u;
                 __syncthreads();
                 if (uni(s_ctl[0]) != 0u) {  // nobody had it: ours now
+                    spins = 0;  // progress
                     if (tid == 0) s_owned[n_owned] = missing;
                     ++n_owned;
                     own_in_regs = false;
                     load_tile(missing, keys, vals_, false);
                     rank_and_publish(shift, table, tag, true);
                 }
-            } else if (spins > SPIN_LIMIT) {
+            }
+            if (spins > SPIN_LIMIT) {
                 if (tid == 0) { st_agent(status, STATUS_TIMEOUT); s_ctl[2] = 1u; }
                 __syncthreads();
                 return false;

@@ -17,6 +17,9 @@
 // ... and in the two-launch mid-size sort every fourth workgroup of K1 behaves as if it had never been dispatched (the
 // others adopt its tile)
 #define GS_FAULT_MID_ABSENT(block) (((GS_EXP)&8) && ((block)&3u) == 1u)
+// ... and, in the build WITHOUT the fallback (-DGS_FALLBACK=0: the one that must report GS_ERR_TIMEOUT), workgroup 2 of K1 claims its
+// tile and never publishes its counts: nobody can adopt a claimed tile, so every waiter must run into its bounded spin
+#define GS_FAULT_MID_SILENT(block) (((GS_EXP)&8) && !GS_FALLBACK && (block) == 2u)
 
 #if (GS_EXP & 2)
 #define GS_TRACE_SETUP()                                                                                                  \

@@ -29,7 +29,8 @@
 //     (identity passes are dropped in pairs, a skewed pass ranks with wave-aggregated adds, a skewed SORT runs every pass on
 //     position chains whose bases the pass before counts while it scatters), and a look-back that waits too long
 //     recounts the missing tile itself, so no workgroup depends on another's progress for more than a bounded time.
-//   * a sort is 6 launches: GlobalHistogram (which also clears the scan state), Scan, 4 x DigitBinningPass.
+//   * a sort is 7 launches: GlobalHistogram (which also clears the scan state), the sum of its workgroups' tables, Scan,
+//     4 x DigitBinningPass.  (ls_kernels.hpp holds a second plan for large keys-only sorts, opt-in.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -156,6 +157,9 @@ constexpr uint32_t SLAB_HIST = SLAB_INFO + MAX_PASSES * INFO_STRIDE + 32;
 // behind the joint tables: what else the histogram kernel tells the Scan kernel (zero between calls, like the tables)
 constexpr uint32_t HIST_TABLE_WORDS = MAX_PASSES * NCH * RADIX;
 constexpr uint32_t HX_SKEW = 0;  // a workgroup found the digit groups of its keys uneven and stopped counting the joint tables
+constexpr uint32_t HX_OR = 1;    // OR of the digit words of all keys (sortable form) ...
+constexpr uint32_t HX_NAND = 2;  // ... and of their complements: a bit set in both varies; a byte clear in their AND is constant — how a
+                                 // sort planned on position chains (its joint tables are incomplete) still finds its identity passes
 constexpr uint32_t HIST_WORDS = HIST_TABLE_WORDS + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                                                                          workgroup's tables, summed by hist_reduce_kernel*/) {
     constexpr int KW = KeyWords<KT>::value;
     constexpr uint32_t NQ = KW == 2 ? MAX_PASSES : 4;  // tables a workgroup can count
-    __shared__ uint32_t s_h[NQ * NCH * RADIX];
+    __shared__ __attribute__((aligned(16))) uint32_t s_h[NQ * NCH * RADIX];  // (read as uint4 for the slice store)
     __shared__ uint32_t s_uneven;  // a digit group of this workgroup's first work item holds more than GS_POS_SHARE of its keys
 #if GS_HIST_REPLICAS
     // Pass-0 digit counts on 32 lane-private replicas, 16-bit counters packed two per dword: dword (d >> 1) * 32 +
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         return q * (RADIX * NCH) + __builtin_amdgcn_ubfe(hi, 8u * (q - 4u) - LOG_NCH, 8u + LOG_NCH);
     };
 
+    uint32_t k_or = 0, k_nand = 0;  // OR of this thread's digit words / of their complements (free: the kernel waits for its LDS adds)
     uint32_t skew_mode = 0;  // bit q (wave-uniform): a dominant bin was seen for byte q; cleared when it fades
     uint32_t sticky[NQ];     // wave-uniform guess of that bin
 #pragma unroll
@@ -448,6 +453,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
             constexpr bool JOINT = decltype(joint_tag)::value != 0;
             GS_ABL_HIST_STREAM_ONLY(t);
             const uint32_t b[4] = {t.x, t.y, t.z, t.w};
+            k_or |= t.x | t.y | t.z | t.w;
+            k_nand |= ~(t.x & t.y & t.z & t.w);
             const uint32_t bh[4] = {th.x, th.y, th.z, th.w};
 #if GS_HIST_REPLICAS
             if (x0 != cur_x0 || since_fold >= HIST_FOLD_CHUNKS) {  // uniform
@@ -608,6 +615,8 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                         } else {
                             kb = to_bits<KT>(keys[i]);
                         }
+                        k_or |= kb;
+                        k_nand |= ~kb;
                         for (uint32_t q = 0; q < np; ++q)
                             if (!(joint_off && q >= 1)) atomicAdd(&s_h[bin_of(kb, kh, q, x0)], 1u);
                     }
@@ -632,6 +641,17 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
     }
     // (measured: accumulating the OR / AND of all keys here, to drop constant bytes in position-chain sorts too, cost 0.08 ms)
     if (tid == 0 && joint_off) atomicOr(&hist[HIST_TABLE_WORDS + HX_SKEW], 1u);
+    if (allow_pos) {  // (only a sort that may end up on position chains needs them: two atomics per wave)
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) {
+            k_or |= __shfl_xor(k_or, dd, 64);
+            k_nand |= __shfl_xor(k_nand, dd, 64);
+        }
+        if (lane == 0) {
+            atomicOr(&hist[HIST_TABLE_WORDS + HX_OR], k_or);
+            atomicOr(&hist[HIST_TABLE_WORDS + HX_NAND], k_nand);
+        }
+    }
     GS_HIST_STAMP(6);
     GS_ABL_CLOCKS_END();
     GS_HIST_STAMPS_OUT();
@@ -730,13 +750,21 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     // permutation; such passes are dropped in PAIRS, so the result still lands in the caller's buffer with no
     // extra copy and no host round trip: every workgroup of a dropped pass exits on its flag word, every other
     // pass learns from its flags which buffer it reads.  A descending sort keeps one pass to do the reversal.
-    // (Position chains: all four passes run — the digit totals behind the first digit are not known here.  A workgroup
-    //  of the histogram kernel whose sample shows a byte with ONE value does not count that byte as uneven, so keys with
-    //  constant bytes and otherwise even digits stay on this path.)
+    // (Position chains: the digit totals behind the first digit are not known here; the OR / AND of all keys, which the histogram
+    //  kernel accumulates on the side, say which bytes are constant — see below.)
     if ((plan & 2u) && !pos) {
 #pragma unroll
         for (uint32_t qq = 0; qq < NPT; ++qq)
             if (qq < np && g_all[qq] == n) atomicOr(&s_triv, 1u << qq);
+    }
+    if ((plan & 2u) && pos && NPT == 4 && tid == 0) {
+        // position chains: the digit totals behind the first digit are incomplete — the OR / AND of all keys say which BYTES are
+        // constant.  The first pass always runs (its chains are the histogram's position segments); passes 1..3 are dropped in pairs.
+        const uint32_t varying = hist[HIST_TABLE_WORDS + HX_OR] & hist[HIST_TABLE_WORDS + HX_NAND];
+        uint32_t t = 0;
+        for (uint32_t qq = 1; qq < np; ++qq)
+            if (((varying >> (8u * qq)) & 255u) == 0u) t |= 1u << qq;
+        if (t) atomicOr(&s_triv, t);
     }
     const bool counted = !pos || q == 0;  // this pass's digit totals g and chain rows hq are complete
     if (counted && g >= (n >> GS_SKEW_SHIFT) + 1u) atomicMax(&s_mode, ((unsigned long long)g << 8) | (255u - tid));  // (ties: the smaller digit)
@@ -929,8 +957,9 @@ __device__ __forceinline__ void binning_body(
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
-        const uint32_t i = blockIdx.x * THREADS + tid;
-        if (i < HIST_WORDS / 4) reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
+        // (grid-stride: a small grid of a 256-thread tuning shape does not cover the 8200 16-byte words with one store per thread)
+        for (uint32_t i = blockIdx.x * THREADS + tid; i < HIST_WORDS / 4; i += gridDim.x * THREADS)
+            reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
     }
     if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
         const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;

@@ -262,7 +262,10 @@ gs_status gs_mgpu_destroy(gs_mgpu* ctx);
  * GPUSORT_MGPU_OVERLAP=0 keeps keys and values in one group, GPUSORT_MGPU_ALLTOALLV=1 uses ncclAllToAllv instead of grouped
  * send / recv (both read at gs_mgpu_create).  GS_ERR_SIZE on EVERY rank if a bucket does not fit `capacity` even at
  * 12-bit-prefix granularity; GS_ERR_COMM on every rank if some rank failed before the histogram gather (see gs_mgpu_check for
- * failures after it). */
+ * failures after it).  ARGUMENT errors (GS_ERR_ARG / GS_ERR_SIZE / GS_ERR_MODE: null or misaligned pointers, n > shard_keys, a
+ * key type other than the three 32-bit ones) are returned BEFORE the first collective, on the calling rank only: like the
+ * arguments of any collective they must be valid on every rank or on none.  64-bit keys are not accepted here: the split
+ * works on the top byte of a 32-bit key and the exchange moves 4-byte keys; sort 64-bit keys per GPU (gs_onesweep_sort_keys). */
 gs_status gs_onesweep_sort_sharded(gs_mgpu* ctx, const void* d_keys, const void* d_vals, uint32_t n, gs_key_type key_type,
                                    void* d_out_keys, void* d_out_vals, uint32_t* out_n, void* stream);
 /* Synchronises `stream` and reports the last call's outcome: GS_ERR_COMM if SOME rank carried an error of its own through the

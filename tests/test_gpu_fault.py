@@ -115,3 +115,27 @@ def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
     secs = float(out.split("seconds")[1].split()[0])
     assert secs < 20.0
     assert "SMALL True" in out
+
+
+def test_mid_route_claimed_but_silent_tile_times_out_instead_of_hanging(gpu):
+    """a tile of the mid-size route that was CLAIMED (so nobody can adopt it) but whose counts never appear.  The
+    waiters' bounded spin must expire — GS_ERR_TIMEOUT, seconds, no hang — also while they keep trying to adopt."""
+    out = _run("libgpusort_fault_nofallback.so", """
+        import sys, time, torch
+        sys.path.insert(0, %r)
+        import gpusorting_amd as g
+        for n, pairs in ((200000, False), ((1 << 20) + 3, True)):
+            k = torch.empty(n, dtype=torch.int32, device="cuda")
+            g.init_random(k, 10, 0)
+            v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+            s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+            t0 = time.time()
+            s.sort(k, v)
+            try:
+                s.check()
+                print("RESULT no-timeout")
+            except g.GpuSortError as e:
+                print("RESULT status", e.status, "seconds", round(time.time() - t0, 3))
+    """)
+    assert out.count("RESULT status 4") == 2, out   # GS_ERR_TIMEOUT
+    assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])

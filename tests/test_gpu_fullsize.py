@@ -126,7 +126,7 @@ def test_2pow28_low_entropy_properties(gpu, andc, pairs):
 
 
 # ---- bit-exact at the headline size ------------------------------------------------------------
-def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0):
+def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0, plan=None):
     """Sort 2^log2n generator keys (seed = log2n as the reference's big sizes, OneSweepDispatcher.cuh:116-128)
     with value = original index and compare keys AND values element for element with the oracle's stable
     order.  The comparison itself runs on the GPU (a gather and two equality reductions: plumbing)."""
@@ -143,6 +143,8 @@ def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0):
     s = gpu.OneSweep(n, order, kt, gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, vb)
     if rank_mode is not None:
         s.set_rank_mode(rank_mode)
+    if plan is not None:
+        s.set_plan(plan)
     s.sort(dk, dv)
     s.check()
     if vb:
@@ -174,11 +176,24 @@ def test_2pow28_pairs_u32_index_exact_vs_oracle(gpu, oracle):
     _exact_case(gpu, oracle, 28, 0, 4)
 
 
-@pytest.mark.parametrize("andc", [0, 4])
+@pytest.mark.parametrize("andc", [0, 1, 2, 3, 4])
 def test_2pow28_pairs_u64_index_exact_vs_oracle(gpu, oracle, andc):
-    """configs[4] bit-exact with value = index (u64), entropy presets 1 and 5 (512 x 32 tiles, late value fetch,
-    skewed ranking at preset 5)."""
+    """configs[4] bit-exact with value = index (u64) at ALL FIVE entropy presets of the reference's sweep
+    (GPUSortingD3D12/Tests.h:383-387,406-410): the default routing sends presets 2..5 to the position-chain
+    kernels (digit_binning_posv_kernel<8>), preset 1 to the plain form (512 x 32 tiles, late value fetch)."""
     _exact_case(gpu, oracle, 28, andc, 8)
+
+
+@pytest.mark.parametrize("andc", [1, 2])
+def test_2pow28_pairs_u32_index_exact_presets_2_3(gpu, oracle, andc):
+    """(u32, u32) pairs at entropy presets 2 and 3, value = index (preset 1: above; preset 4: below)."""
+    _exact_case(gpu, oracle, 28, andc, 4)
+
+
+@pytest.mark.parametrize("andc", [0, 2])
+def test_2pow28_keys_exact_local_sort_plan(gpu, oracle, andc):
+    """The opt-in local-sort plan (gs_onesweep_set_plan; ls_kernels.hpp) at the headline size, uniform and skewed keys."""
+    _exact_case(gpu, oracle, 28, andc, 0, plan=1)
 
 
 def test_2pow26_pairs_ballot_ranking_exact_vs_oracle(gpu, oracle):

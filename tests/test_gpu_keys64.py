@@ -104,7 +104,7 @@ def test_keys64_each_of_the_eight_passes(gpu, oracle):
     s.close()
 
 
-def test_keys64_2pow24_exact(gpu, oracle):
+def test_keys64_2pow24_exact(gpu, oracle, routing):
     """A multi-thousand-tile case (2^24 + 12345 keys, value = index) and its throughput for the record."""
     import time
     import torch

@@ -82,7 +82,7 @@ BIG_SIZES = ((1 << 20) + 1, (1 << 20) + 12345, (1 << 21) - 7, 1 << 21, (1 << 21)
 
 @pytest.mark.parametrize("vb", [0, 4, 8])
 @pytest.mark.parametrize("kind", ["uniform", "preset4", "top-constant"])
-def test_mid_path_larger_tile_classes(gpu, oracle, vb, kind):
+def test_mid_path_larger_tile_classes(gpu, oracle, routing, vb, kind):
     rng = np.random.default_rng(23 + vb)
     for n in BIG_SIZES:
         if vb == 8 and n > (1 << 21):
@@ -102,7 +102,7 @@ def test_mid_path_larger_tile_classes(gpu, oracle, vb, kind):
 
 
 @pytest.mark.parametrize("kt,order,rank", [(1, 1, 1), (2, 0, 0), (2, 1, 1), (0, 1, 0)])
-def test_mid_path_larger_tile_classes_types(gpu, oracle, kt, order, rank):
+def test_mid_path_larger_tile_classes_types(gpu, oracle, routing, kt, order, rank):
     rng = np.random.default_rng(31)
     for n, vb in (((1 << 21) - 1, 4), ((1 << 22) - 3, 0)):
         keys = _keys(oracle, rng, n, "uniform")

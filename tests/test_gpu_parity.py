@@ -27,21 +27,10 @@ def to_host(t, dtype):
     return t.cpu().numpy().view(dtype)
 
 
-@pytest.fixture(autouse=True, params=["default-routing", "general-path", "position-chains"])
-def routing(request, monkeypatch):
-    """Every test of this file runs three times: with the library's own routing (single-tile kernel for small n, the
-    two-launch MSD + bucket sort up to 2^20 keys, the six-launch pipeline above); with the mid-size route
-    switched off, so that the general pipeline stays covered at the sizes the mid-size route now takes; and with
-    every keys-only sort of 2^20 32-bit keys or more forced onto the position-chain plan (PF_POS: all four passes on
-    position chains, each counting the next one's digit while it scatters — the plan skewed keys get at 2^25 keys and
-    more), whatever the keys look like."""
-    if request.param == "general-path":
-        monkeypatch.setenv("GPUSORT_MID_PATH", "0")
-    if request.param == "position-chains":
-        monkeypatch.setenv("GPUSORT_MID_PATH", "0")
-        monkeypatch.setenv("GPUSORT_POS", "2")
-        monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "20")
-    return request.param
+@pytest.fixture(autouse=True)
+def _every_test_under_three_routings(routing):
+    """(tests/conftest.py: the library's own routing, the mid-size route off, forced position chains)"""
+    return routing
 
 
 @pytest.fixture(scope="module")
@@ -549,12 +538,10 @@ def test_identity_passes_dropped_on_device(gpu, oracle, P, skip, vb, kt, order):
 
 
 def test_dropped_passes_cost_nothing(gpu, routing):
-    """16-bit keys: passes 2 and 3 must be launches of workgroups that exit at once.  (Constant bytes do not count as
-    skew — the default routing keeps such keys on the plan that drops their passes; FORCED onto position chains, whose
-    passes learn their digit counts only from the pass before, all four passes run.)"""
+    """16-bit keys: passes 2 and 3 must be launches of workgroups that exit at once — on the position-chain plan too (its passes
+    learn their digit counts only from the pass before; the OR / AND of all keys, accumulated by the histogram kernel, tell the
+    Scan kernel which bytes are constant)."""
     import torch
-    if routing == "position-chains":
-        pytest.skip("the forced position-chain plan never drops a pass")
     n = 1 << 24
     k = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device="cuda")
     s = gpu.OneSweep(n)
