@@ -27,6 +27,65 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp), _u32p, _u32p, _u32p, _u32p, _u32p, _vp)
 
 
+class OneSweepOptions(C.Structure):
+    """gs_onesweep_options (include/gpusort.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("shape_threads", C.c_uint32), ("shape_keys_per_thread", C.c_uint32),
+                ("rank_mode", C.c_int32), ("small_path", C.c_int32), ("mid_path", C.c_int32), ("skip_passes", C.c_int32),
+                ("position_chains", C.c_int32), ("position_chains_min_log2", C.c_uint32), ("key64_sweeps", C.c_int32),
+                ("plan", C.c_int32), ("first_pass_big", C.c_int32), ("hist_blocks", C.c_uint32), ("debug_flags", C.c_uint32)]
+
+
+class MgpuOptions(C.Structure):
+    """gs_mgpu_options (include/gpusort.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("force_exchange", C.c_int32), ("overlap", C.c_int32), ("alltoallv", C.c_int32),
+                ("sorter", OneSweepOptions)]
+
+
+def onesweep_options_from_env(**overrides) -> "OneSweepOptions":
+    """The library reads no environment variables; this harness does: GPUSORT_* names (tests, tools/, A/B runs) are
+    translated into gs_onesweep_options here.  Keyword arguments win over the environment."""
+    o = OneSweepOptions()
+    load().gs_onesweep_options_default(C.byref(o))
+    env = os.environ
+    if "GPUSORT_SHAPE" in env:  # "512x16"
+        try:
+            t, k = env["GPUSORT_SHAPE"].lower().split("x")
+            o.shape_threads, o.shape_keys_per_thread = int(t), int(k)
+        except ValueError:
+            pass
+    for name, field in (("GPUSORT_RANK", "rank_mode"), ("GPUSORT_SMALL_PATH", "small_path"), ("GPUSORT_MID_PATH", "mid_path"),
+                        ("GPUSORT_SKIP_PASSES", "skip_passes"), ("GPUSORT_POS", "position_chains"),
+                        ("GPUSORT_POS_MIN_LOG2", "position_chains_min_log2"), ("GPUSORT_KEY64_SWEEPS", "key64_sweeps"),
+                        ("GPUSORT_PLAN", "plan"), ("GPUSORT_FIRST_PASS_BIG", "first_pass_big"), ("GPUSORT_HIST_BLOCKS", "hist_blocks"),
+                        ("GPUSORT_LS_EXP", "debug_flags"), ("GPUSORT_EXPMODE", "debug_flags")):
+        if name in env:
+            try:
+                setattr(o, field, int(env[name], 0))
+            except ValueError:
+                pass
+    for k, v in overrides.items():
+        if v is not None:
+            setattr(o, k, int(v))
+    return o
+
+
+def mgpu_options_from_env(**overrides) -> "MgpuOptions":
+    o = MgpuOptions()
+    load().gs_mgpu_options_default(C.byref(o))
+    o.sorter = onesweep_options_from_env()  # the context's local sorter follows the same GPUSORT_* switches
+    for name, field in (("GPUSORT_MGPU_FORCE_EXCHANGE", "force_exchange"), ("GPUSORT_MGPU_OVERLAP", "overlap"),
+                        ("GPUSORT_MGPU_ALLTOALLV", "alltoallv")):
+        if name in os.environ:
+            try:
+                setattr(o, field, int(os.environ[name], 0))
+            except ValueError:
+                pass
+    for k, v in overrides.items():
+        if v is not None:
+            setattr(o, k, int(v))
+    return o
+
+
 class MgpuTransport(C.Structure):
     _fields_ = [("user", _vp), ("all_gather_u32", ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
 
@@ -36,6 +95,8 @@ _PROTOS = [
     ("gs_status_string", C.c_char_p, [_int]),
     ("gs_last_hip_error", _int, []),
     ("gs_onesweep_create", _int, [C.POINTER(_vp), _u32, _int, _u32]),
+    ("gs_onesweep_options_default", None, [_vp]),
+    ("gs_onesweep_create_ex", _int, [C.POINTER(_vp), _u32, _int, _u32, _vp]),
     ("gs_onesweep_destroy", _int, [_vp]),
     ("gs_onesweep_temp_bytes", C.c_size_t, [_u32]),
     ("gs_onesweep_partition_size", _u32, [_int, _u32]),
@@ -68,6 +129,10 @@ _PROTOS = [
     ("gs_onesweep_msd_fine_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_mgpu_get_unique_id", _int, [_u8p]),
     ("gs_mgpu_create", _int, [C.POINTER(_vp), _u8p, _u32, _u32, _u32, _u32, _int, _u32]),
+    ("gs_mgpu_options_default", None, [_vp]),
+    ("gs_mgpu_create_ex", _int, [C.POINTER(_vp), _u8p, _u32, _u32, _u32, _u32, _int, _u32, _vp]),
+    ("gs_mgpu_set_alltoallv", _int, [_vp, _int]),
+    ("gs_mgpu_create_with_transport_ex", _int, [C.POINTER(_vp), C.POINTER(MgpuTransport), _u32, _u32, _u32, _u32, _int, _u32, _vp]),
     ("gs_mgpu_destroy", _int, [_vp]),
     ("gs_onesweep_sort_sharded", _int, [_vp, _vp, _vp, _u32, _int, _vp, _vp, _u32p, _vp]),
     ("gs_mgpu_get_profile", _int, [_vp, C.POINTER(C.c_float), _u64p, _u64p, _u32p]),

@@ -197,13 +197,13 @@ struct gs_onesweep {
     gs_mode mode;
     uint32_t value_bytes;
     int shape;
-    int shape_auto;  // 1 = the library picks (mid sizes use MID_SHAPE); 0 after gs_onesweep_set_shape / GPUSORT_SHAPE
+    int shape_auto;  // 1 = the library picks (mid sizes use MID_SHAPE); 0 after gs_onesweep_set_shape / gs_onesweep_options::shape_*
     int small_path; // 1 = single-tile kernel for n <= SMALL_TILE (default), 0 = always the tiled path
     int mid_path;    // 1 = two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (default), 0 = the six-launch path
     int skip_passes; // 1 = identity passes (one digit value for all keys) are dropped in pairs (default)
     int pos_chains;  // keys-only sorts of skewed 32-bit keys run every pass on position chains: 1 allowed (default), 0 never
-    int key64_sweeps;       // 64-bit keys: 1 = one GlobalHistogram + Scan for all eight passes (default), 2 = one per word (GPUSORT_KEY64_SWEEPS; A/B, tests)
-    uint32_t pos_min_keys;  // ... from this many keys up (default 2^25 + 1: where the big tile shape takes over; GPUSORT_POS_MIN_LOG2)
+    int key64_sweeps;       // 64-bit keys: 1 = one GlobalHistogram + Scan for all eight passes (default), 2 = one per word (gs_onesweep_options::key64_sweeps; A/B, tests)
+    uint32_t pos_min_keys;  // ... from this many keys up (default 2^25 + 1: where the big tile shape takes over; gs_onesweep_options::position_chains_min_log2)
     int rank_mode;  // 0 ballot multi-split, 1 returning LDS atomic (needs the lane-order probe to pass)
     uint32_t* slab;
     size_t slab_words;
@@ -221,6 +221,9 @@ struct gs_onesweep {
     uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
     // local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys from ls_min_keys up
+    uint32_t hist_blocks_opt;  // gs_onesweep_options::hist_blocks (0 = the library picks)
+    int first_pass_big;        // gs_onesweep_options::first_pass_big
+    uint32_t debug_flags;      // gs_onesweep_options::debug_flags
     int ls_plan;           // 1 = the local-sort plan for eligible sorts (gs_onesweep_set_plan), 0 = never (default)
     uint32_t ls_min_keys;
     uint32_t* ls_runs;     // run table of the first kernel: [256][ls_nt_pad] words
@@ -254,7 +257,7 @@ inline hipError_t zero_hist(gs_onesweep* h, hipStream_t s) {  // the HIST region
 const HistLauncher g_hist[6] = {launch_hist<0>, launch_hist<1>, launch_hist<2>, launch_hist<3>, launch_hist<4>, launch_hist<5>};
 inline bool is_key64(gs_key_type kt) { return (int)kt >= 3; }
 
-uint32_t hist_blocks(uint32_t n) {
+uint32_t hist_blocks(uint32_t n, uint32_t forced = 0) {
     // one chunk per workgroup at mid sizes (measured: 4/8/16 chunks per workgroup — fewer closing global atomics,
     // less parallelism — are slower: 11 -> 15-23 us at 2^16..2^20)
     // Above that ONE workgroup per CU (half of them up to 2^22 keys): every workgroup closes with one global atomic per
@@ -269,8 +272,7 @@ uint32_t hist_blocks(uint32_t n) {
     }();
     const uint32_t want = div_up(n, gs::HIST_CHUNK);
     const uint32_t cap = n <= (1u << 22) ? (cus + 1) / 2 : cus;
-    static const int forced = getenv("GPUSORT_HIST_BLOCKS") ? atoi(getenv("GPUSORT_HIST_BLOCKS")) : 0;  // tuning aid
-    if (forced > 0) return (uint32_t)forced < want ? (uint32_t)forced : want;
+    if (forced > 0) return forced < want ? forced : want;  // gs_onesweep_options::hist_blocks (tuning aid)
     return want < 1 ? 1 : (want > cap ? cap : want);
 }
 
@@ -285,11 +287,10 @@ uint32_t pos_grid() {
 }
 
 // most workgroups the histogram kernel is ever launched with for a handle of max_keys keys (sizes its slices)
-uint32_t hist_blocks_cap(uint32_t max_keys) {
+uint32_t hist_blocks_cap(uint32_t max_keys, uint32_t forced = 0) {
     uint32_t m = hist_blocks(max_keys);
     if (max_keys > (1u << 22)) { const uint32_t b = hist_blocks(1u << 22); m = b > m ? b : m; }
-    static const int forced = getenv("GPUSORT_HIST_BLOCKS") ? atoi(getenv("GPUSORT_HIST_BLOCKS")) : 0;
-    if (forced > 0 && (uint32_t)forced > m) m = (uint32_t)forced;
+    if (forced > m) m = forced;
     return m;
 }
 
@@ -330,7 +331,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (rec) GS_HIP(hipEventRecord(h->ev[0], s));
     if (rec) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
-    g_hist[kt](s, hist_blocks(n), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
+    g_hist[kt](s, hist_blocks(n, h->hist_blocks_opt), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
                (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u, h->partials);
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
@@ -488,7 +489,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         uint32_t* runs_t = h->ls_runs + (size_t)gs::RADIX * h->ls_nt_pad;  // the first kernel's rows [tile][256]; transposed into ls_runs
         uint32_t* eprefix = runs_t + (size_t)gs::RADIX * h->ls_nt_pad;
         uint32_t* stab = eprefix + (size_t)gs::RADIX * h->ls_nt_pad;
-        static const uint32_t ls_exp = getenv("GPUSORT_LS_EXP") ? (uint32_t)strtoul(getenv("GPUSORT_LS_EXP"), nullptr, 0) : 0u;  // tuning bits
+        const uint32_t ls_exp = h->debug_flags;  // tuning bits (gs_onesweep_options::debug_flags)
         g_ls_first[kt](s, grid, ka, kb, runs_t, slices, h->slab, zero_end, n, 2u | ls_exp);
         const uint32_t tblocks = div_up(nt, 64u);
         hipLaunchKernelGGL(gs::ls_plan_kernel, dim3(tblocks + gs::LS_SLICE_WORDS / 64u), dim3(gs::LS_RED_THREADS), 0, s, runs_t, h->ls_runs, nt, h->ls_nt_pad, tblocks,
@@ -520,9 +521,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // Mid sizes, keys-only (2^22 < n <= 2^25: the 8192-key tile): the FIRST pass runs on the 16 384-key tile.  Its position segments are
     // whole tiles (prologue), so 2^24 keys are exactly 1024 tiles — two launch rounds on the 512 slots of that shape instead of three
     // rounds of 8192-key tiles on 768 — and its input is cold, which the larger tile streams better; the later passes' chains are
-    // digit groups with a partial tile at each end, which overflow the round.  GPUSORT_FIRST_PASS_BIG=0 switches it off (A/B).
-    static const bool first_big_env = !(getenv("GPUSORT_FIRST_PASS_BIG") && atoi(getenv("GPUSORT_FIRST_PASS_BIG")) == 0);
-    const int shape0 = (first_big_env && h->shape_auto && shape == MID_SHAPE && vb == 0 && !is_key64(kt) && n > (1u << 22) &&
+    // digit groups with a partial tile at each end, which overflow the round.  gs_onesweep_options::first_pass_big = 0 switches it off (A/B).
+    const int shape0 = (h->first_pass_big && h->shape_auto && shape == MID_SHAPE && vb == 0 && !is_key64(kt) && n > (1u << 22) &&
                         g_shapes[0].fn[h->rank_mode][0][kt] != nullptr) ? 0 : shape;
     BinLauncher fn0 = g_shapes[shape0].fn[h->rank_mode][vb_index(vb)][kt];
     // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
@@ -530,7 +530,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const uint32_t dyn = h->skip_passes ? 2u : 0u;
     // bit 2: the sort may run on position chains in every pass (PF_POS; decided on the device: the histogram kernel finds the
     // digit groups uneven, the Scan kernel plans accordingly) — every pass is then launched in both chain forms and the
-    // plan says which one works.  Keys-only sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; GPUSORT_POS=0
+    // plan says which one works.  Keys-only sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; gs_onesweep_options::position_chains = 0
     // switches it off.
     const bool pos = dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
                      (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
@@ -539,7 +539,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
     // chains of pass 4 are the groups of byte 3's values, as inside a word) — identity passes are dropped in pairs across the
-    // whole key (keys below 2^32: four passes).  GPUSORT_KEY64_SWEEPS=2 (A/B) or a caller-picked tile too small for the slab's
+    // whole key (keys below 2^32: four passes).  key64_sweeps = 2 (A/B) or a caller-picked tile too small for the slab's
     // eight descriptor regions: two rounds of histogram + scan + 4 passes — the low word's bytes, then (stable) the high
     // word's; each round leaves its result in the caller's buffers, only the last one carries the descending reversal.
     const bool one_sweep = is_key64(kt) && h->key64_sweeps == 1 &&
@@ -547,7 +547,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const uint32_t rounds = (is_key64(kt) && !one_sweep) ? 2u : 1u;
     const uint32_t NP = one_sweep ? gs::MAX_PASSES : 4u;
 #if (GS_EXP & (1024 | 2048))
-    const uint32_t exp_mode = getenv("GPUSORT_EXPMODE") ? (uint32_t)atoi(getenv("GPUSORT_EXPMODE")) & (256u | 512u | 1024u | 2048u) : 0u;
+    const uint32_t exp_mode = h->debug_flags & (256u | 512u | 1024u | 2048u);
     h->exp_keep_desc = (exp_mode & 256u) != 0u;
 #else
     const uint32_t exp_mode = 0u;
@@ -645,9 +645,43 @@ uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes) {
     return (uint32_t)sh.threads * sh.kpt;
 }
 
+void gs_onesweep_options_default(gs_onesweep_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
+    o->rank_mode = -1;
+    o->small_path = 1;
+    o->mid_path = 1;
+    o->skip_passes = 1;
+    o->position_chains = 1;
+    o->position_chains_min_log2 = 25;
+    o->key64_sweeps = 1;
+    o->plan = 0;
+    o->first_pass_big = 1;
+}
+
 gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes) {
+    return gs_onesweep_create_ex(out, max_keys, mode, value_bytes, nullptr);
+}
+
+gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes, const gs_onesweep_options* options) {
     if (!out) return GS_ERR_ARG;
     *out = nullptr;
+    gs_onesweep_options o;
+    gs_onesweep_options_default(&o);
+    if (options) {
+        if (options->struct_size != sizeof(gs_onesweep_options)) return GS_ERR_ARG;  // (one layout so far)
+        o = *options;
+    }
+    if (o.rank_mode < -1 || o.rank_mode > 1 || o.position_chains < 0 || o.position_chains > 2 || o.plan < 0 || o.plan > 2 ||
+        (o.key64_sweeps != 1 && o.key64_sweeps != 2) || o.position_chains_min_log2 < 20 || o.position_chains_min_log2 > 30)
+        return GS_ERR_ARG;
+    int shape_pick = -1;
+    if (o.shape_threads || o.shape_keys_per_thread) {
+        for (int i = 0; i < g_num_shapes; ++i)
+            if ((uint32_t)g_shapes[i].threads == o.shape_threads && (uint32_t)g_shapes[i].kpt == o.shape_keys_per_thread) shape_pick = i;
+        if (shape_pick < 0) return GS_ERR_ARG;
+    }
     if (max_keys == 0 || max_keys > GS_MAX_KEYS) return GS_ERR_SIZE;
     if (mode == GS_MODE_KEYS_ONLY) {
         if (value_bytes != 0) return GS_ERR_MODE;
@@ -665,22 +699,16 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->value_bytes = value_bytes;
     h->shape = (mode == GS_MODE_PAIRS && value_bytes == 4) ? 1 : 0;
     h->shape_auto = 1;
-    h->rank_mode = 0;
-    h->small_path = 1;
-    if (const char* env = getenv("GPUSORT_SMALL_PATH")) h->small_path = atoi(env) ? 1 : 0;
-    h->pos_chains = 1;
-    h->pos_min_keys = (1u << 25) + 1u;
-    if (const char* env = getenv("GPUSORT_POS_MIN_LOG2")) {
-        const int lg = atoi(env);
-        if (lg >= 20 && lg <= 30) h->pos_min_keys = 1u << lg;
-    }
-    if (const char* env = getenv("GPUSORT_POS")) h->pos_chains = atoi(env);  // 0 never, 1 when the keys are skewed, 2 always (tests, tuning)
-    if (h->pos_chains < 0 || h->pos_chains > 2) h->pos_chains = 1;
-    h->key64_sweeps = (getenv("GPUSORT_KEY64_SWEEPS") && atoi(getenv("GPUSORT_KEY64_SWEEPS")) == 2) ? 2 : 1;
-    h->skip_passes = 1;
-    if (const char* env = getenv("GPUSORT_SKIP_PASSES")) h->skip_passes = atoi(env) ? 1 : 0;
-    h->mid_path = 1;
-    if (const char* env = getenv("GPUSORT_MID_PATH")) h->mid_path = atoi(env) ? 1 : 0;
+    if (shape_pick >= 0) { h->shape = shape_pick; h->shape_auto = 0; }
+    h->small_path = o.small_path ? 1 : 0;
+    h->pos_chains = o.position_chains;
+    h->pos_min_keys = o.position_chains_min_log2 == 25 ? (1u << 25) + 1u : 1u << o.position_chains_min_log2;
+    h->key64_sweeps = o.key64_sweeps;
+    h->skip_passes = o.skip_passes ? 1 : 0;
+    h->mid_path = o.mid_path ? 1 : 0;
+    h->hist_blocks_opt = o.hist_blocks;
+    h->first_pass_big = o.first_pass_big ? 1 : 0;
+    h->debug_flags = o.debug_flags;
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;
@@ -690,7 +718,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     h->msd_keys = nullptr;
     h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
     h->hist_dirty = false;
-    h->ls_plan = 0;  // opt-in (gs_onesweep_set_plan) until it beats the GlobalHistogram / Scan / 4-pass pipeline on uniform keys
+    h->ls_plan = 0;  // opt-in until it beats the GlobalHistogram / Scan / 4-pass pipeline on uniform keys (set below once the tables exist)
     h->ls_min_keys = (1u << 25) + 1u;  // (below: the 8192-key tile and the two-launch routes)
     h->ls_runs = nullptr;
     h->ls_nt_pad = ls_nt_pad_for(max_keys);
@@ -701,17 +729,10 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
     // Tile ranking: the returning-LDS-atomic path needs same-address lanes of one
     // wave-instruction served in ascending lane order.  Probe the device once per
     // process; fall back to the ballot multi-split if a single lane disagrees.
-    h->rank_mode = lds_atomic_order_ok() ? 1 : 0;
-    if (const char* env = getenv("GPUSORT_RANK")) h->rank_mode = atoi(env) == 1 ? 1 : 0;
-    if (const char* env = getenv("GPUSORT_SHAPE")) {  // e.g. "512x16"
-        int t = 0, k = 0;
-        if (sscanf(env, "%dx%d", &t, &k) == 2)
-            for (int i = 0; i < g_num_shapes; ++i)
-                if (g_shapes[i].threads == t && g_shapes[i].kpt == k) { h->shape = i; h->shape_auto = 0; }
-    }
+    h->rank_mode = o.rank_mode >= 0 ? o.rank_mode : (lds_atomic_order_ok() ? 1 : 0);
     h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&h->partials, (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&h->partials, (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS * sizeof(uint32_t));
     if (e == hipSuccess && mode == GS_MODE_KEYS_ONLY && max_keys >= h->ls_min_keys)  // the run table of the local-sort plan (16 MiB at 2^28 keys)
         e = hipMalloc(&h->ls_runs, ls_table_words(max_keys) * sizeof(uint32_t));  // run table, its prefix, tile -> run table (16 + 16 + 16 MiB at 2^28 keys)
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
@@ -725,6 +746,7 @@ gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode,
         delete h;
         return GS_ERR_HIP;
     }
+    if (o.plan != 0 && h->ls_runs) h->ls_plan = o.plan;  // (a handle without the plan's tables stays on the default pipeline)
     *out = h;
     return GS_OK;
 }

@@ -20,7 +20,7 @@
 // Why grouped send/recv and not ncclAllToAllv (rccl.h:815, the call BASELINE.json names): RCCL implements AllToAllv as
 // exactly this group of sends and receives, but through one entry point that takes ONE buffer pair — keys and values
 // would be two calls on one communicator, serialised, and the call cannot skip empty peers or put a peer's two arrays
-// back to back.  GPUSORT_MGPU_ALLTOALLV=1 switches the exchange to ncclAllToAllv (one call per array) for comparison on
+// back to back.  gs_mgpu_options::alltoallv = 1 (or gs_mgpu_set_alltoallv) switches the exchange to ncclAllToAllv (one call per array) for comparison on
 // hardware; results are identical.
 // FAILURES.  A rank that fails alone must not leave its peers inside a collective.  Before the gather (histogram,
 // allocation, launch errors): the rank gathers a POISONED row (MSD_POISON in bin 0), the plan kernel of every rank sees
@@ -93,7 +93,7 @@ thread_local int g_last_rccl_error = 0;
 struct RcclTransport {
     void* comm;
     uint32_t rank, world;
-    int alltoallv;  // exchange through ncclAllToAllv instead of grouped send / recv (GPUSORT_MGPU_ALLTOALLV)
+    int alltoallv;  // exchange through ncclAllToAllv instead of grouped send / recv (gs_mgpu_options::alltoallv, gs_mgpu_set_alltoallv)
 };
 
 int rccl_all_gather_u32(void* user, const void* d_send, void* d_recv, size_t count, void* stream) {
@@ -168,7 +168,8 @@ struct gs_mgpu {
     hipEvent_t ev_part, ev_vals, ev_tail;
     uint32_t *d_status;        // [0] this rank's status of the running call, [1 .. world] every rank's (gathered)
     uint32_t* h_status;        // pinned mirror
-    int overlap;               // values on the second stream (GPUSORT_MGPU_OVERLAP, default 1)
+    int overlap;               // values on the second stream (gs_mgpu_options::overlap, default 1)
+    int alltoallv;             // the RCCL transport exchanges through ncclAllToAllv (gs_mgpu_options::alltoallv)
     int failed;                // a call on this context has failed: destroy aborts the communicators
     int debug_fail;            // test hook: 1 = fail before the gather, 2 = fail after the plan (next call only)
     uint32_t *part_keys;       // shard grouped by destination; alt buffer of the local sort afterwards
@@ -206,20 +207,25 @@ gs_status mgpu_alloc(gs_mgpu* c) {
 }
 
 gs_status mgpu_new(gs_mgpu** out, uint32_t rank, uint32_t world, uint32_t shard_keys, uint32_t capacity, gs_mode mode,
-                   uint32_t value_bytes) {
+                   uint32_t value_bytes, const gs_mgpu_options* options) {
     if (!out) return GS_ERR_ARG;
     *out = nullptr;
+    gs_mgpu_options o;
+    gs_mgpu_options_default(&o);
+    if (options) {
+        if (options->struct_size != sizeof(gs_mgpu_options)) return GS_ERR_ARG;
+        o = *options;
+    }
     if (world == 0 || world > gs::MSD_MAX_WORLD || rank >= world) return GS_ERR_ARG;
     if (shard_keys == 0 || shard_keys > GS_MAX_KEYS || capacity < shard_keys || capacity > GS_MAX_KEYS) return GS_ERR_SIZE;
     gs_mgpu* c = new (std::nothrow) gs_mgpu();
     if (!c) return GS_ERR_ARG;
     c->rank = rank; c->world = world; c->shard_keys = shard_keys; c->capacity = capacity;
     c->mode = mode; c->value_bytes = mode == GS_MODE_PAIRS ? value_bytes : 0;
-    c->force_exchange = 0;
-    if (const char* env = getenv("GPUSORT_MGPU_FORCE_EXCHANGE")) c->force_exchange = atoi(env) ? 1 : 0;
-    c->overlap = 1;
-    if (const char* env = getenv("GPUSORT_MGPU_OVERLAP")) c->overlap = atoi(env) ? 1 : 0;
-    gs_status st = gs_onesweep_create(&c->sorter, capacity, mode, value_bytes);
+    c->force_exchange = o.force_exchange ? 1 : 0;
+    c->overlap = o.overlap ? 1 : 0;
+    c->alltoallv = o.alltoallv ? 1 : 0;
+    gs_status st = gs_onesweep_create_ex(&c->sorter, capacity, mode, value_bytes, o.sorter.struct_size ? &o.sorter : nullptr);
     if (st == GS_OK) st = mgpu_alloc(c);
     if (st != GS_OK) { gs_mgpu_destroy(c); return st; }
     *out = c;
@@ -275,12 +281,32 @@ gs_status gs_mgpu_get_unique_id(uint8_t id[GS_MGPU_UNIQUE_ID_BYTES]) {
     return GS_OK;
 }
 
+void gs_mgpu_options_default(gs_mgpu_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
+    o->overlap = 1;
+}
+
 gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
                          uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes) {
+    return gs_mgpu_create_ex(out, id, rank, world, shard_keys, capacity, mode, value_bytes, nullptr);
+}
+
+gs_status gs_mgpu_set_alltoallv(gs_mgpu* c, int on) {
+    if (!c) return GS_ERR_ARG;
+    c->alltoallv = on ? 1 : 0;
+    c->rccl_state.alltoallv = c->alltoallv;
+    c->rccl_state2.alltoallv = c->alltoallv;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_create_ex(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
+                            uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes, const gs_mgpu_options* options) {
     if (!id) return GS_ERR_ARG;
     Rccl* r = rccl();
     if (!r) return GS_ERR_COMM;
-    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes);
+    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes, options);
     if (st != GS_OK) return st;
     gs_mgpu* c = *out;
     Rccl::UniqueId u;
@@ -293,7 +319,7 @@ gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES
         *out = nullptr;
         return GS_ERR_COMM;
     }
-    const int a2av = getenv("GPUSORT_MGPU_ALLTOALLV") ? atoi(getenv("GPUSORT_MGPU_ALLTOALLV")) : 0;
+    const int a2av = c->alltoallv;
     c->rccl_state = RcclTransport{comm, rank, world, a2av};
     c->owns_comm = true;
     c->transport = gs_mgpu_transport{&c->rccl_state, rccl_all_gather_u32, rccl_exchange};
@@ -314,8 +340,13 @@ gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES
 
 gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* t, uint32_t rank, uint32_t world,
                                         uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes) {
+    return gs_mgpu_create_with_transport_ex(out, t, rank, world, shard_keys, capacity, mode, value_bytes, nullptr);
+}
+
+gs_status gs_mgpu_create_with_transport_ex(gs_mgpu** out, const gs_mgpu_transport* t, uint32_t rank, uint32_t world,
+                                           uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes, const gs_mgpu_options* options) {
     if (!t || !t->all_gather_u32 || !t->exchange) return GS_ERR_ARG;
-    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes);
+    gs_status st = mgpu_new(out, rank, world, shard_keys, capacity, mode, value_bytes, options);
     if (st != GS_OK) return st;
     (*out)->transport = *t;
     (*out)->transport2 = *t;

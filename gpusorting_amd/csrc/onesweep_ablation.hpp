@@ -56,7 +56,7 @@
 #define GS_ABL_COUNT_NEXT(kb, o) do { } while (0)
 #endif
 // 1024: the look-back / scatter decomposition of round 3 (tools/r03_ablate.py); the variants are RUNTIME bits of the
-//       kernel's mode word (GPUSORT_EXPMODE, read by the host at every sort), so one build serves every combination:
+//       kernel's mode word (gs_onesweep_options::debug_flags), so one build serves every combination:
 //         mode 256   replay: the descriptors of an identical earlier sort are still in the slab (the histogram kernel
 //                    does not clear them) and no tile publishes REDUCTION, so every look-back finds its predecessor's
 //                    INCLUSIVE row in its first read — a look-back of exactly one round trip, exact positions

@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void binning_body(
     if (uni(s_misc[3]) != STATUS_OK) break;
     const uint32_t pflags = uni(s_misc[9]) | (pos_skew ? PF_SKEW : 0u);
     if ((mode & 2u) && (pflags & PF_SKIP)) break;  // identity pass of a full sort
-#ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with GPUSORT_SKIP_PASSES=0)
+#ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with skip_passes = 0)
     const bool swapped = false;
 #else
     const bool swapped = (mode & 2u) && (pflags & PF_SRC_ALT);

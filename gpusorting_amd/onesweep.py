@@ -88,7 +88,10 @@ class OneSweep:
     """One sorter object == one ``gs_onesweep`` handle (scan state) + lazily sized alt buffers."""
 
     def __init__(self, max_keys: int, order: int = ORDER_ASCENDING, key_type: int = KEY_UINT32,
-                 mode: int = MODE_KEYS_ONLY, value_bytes: int = 0, device: int | None = None):
+                 mode: int = MODE_KEYS_ONLY, value_bytes: int = 0, device: int | None = None, **options):
+        """``options``: fields of ``gs_onesweep_options`` (include/gpusort.h), e.g. ``mid_path=0``, ``plan=1``; what is not given
+        comes from the GPUSORT_* environment variables of the test / tuning harness (``_lib.onesweep_options_from_env``), then
+        from the library's defaults.  The library itself reads no environment."""
         if not torch.cuda.is_available():
             raise RuntimeError("gpusorting_amd needs a GPU: the product path has no CPU fallback")
         self._lib = _lib.load()
@@ -101,7 +104,8 @@ class OneSweep:
         if mode == MODE_PAIRS and self.value_bytes == 0:
             self.value_bytes = 4
         h = C.c_void_p()
-        check(self._lib.gs_onesweep_create(C.byref(h), self.max_keys, mode, self.value_bytes), "gs_onesweep_create")
+        opts = _lib.onesweep_options_from_env(**options)
+        check(self._lib.gs_onesweep_create_ex(C.byref(h), self.max_keys, mode, self.value_bytes, C.byref(opts)), "gs_onesweep_create_ex")
         self._h = h
         self._alt_keys = None
         self._alt_vals = None

@@ -214,9 +214,10 @@ class ShardedOneSweep:
         ctx = C.c_void_p()
         if dist.get_backend(self.group) == "gloo":
             self._transport = _HostStagedTransport(self.group, self.rank, self.world)
-            st = lib.gs_mgpu_create_with_transport(C.byref(ctx), C.byref(self._transport.struct), self.rank, self.world,
-                                                   self.shard_keys, self.capacity, mode, self.value_bytes)
-            _lib.check(st, "gs_mgpu_create_with_transport")
+            mopts = _lib.mgpu_options_from_env()
+            st = lib.gs_mgpu_create_with_transport_ex(C.byref(ctx), C.byref(self._transport.struct), self.rank, self.world,
+                                                      self.shard_keys, self.capacity, mode, self.value_bytes, C.byref(mopts))
+            _lib.check(st, "gs_mgpu_create_with_transport_ex")
         else:
             uid = torch.zeros(_lib.GS_MGPU_UNIQUE_ID_BYTES, dtype=torch.uint8)
             if self.rank == 0:
@@ -227,8 +228,9 @@ class ShardedOneSweep:
             src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
             dist.broadcast(uid, src, group=self.group)  # the only thing torch.distributed carries: 128 bytes, once
             raw = (C.c_uint8 * _lib.GS_MGPU_UNIQUE_ID_BYTES)(*uid.cpu().tolist())
-            _lib.check(lib.gs_mgpu_create(C.byref(ctx), raw, self.rank, self.world, self.shard_keys, self.capacity, mode,
-                                          self.value_bytes), "gs_mgpu_create")
+            mopts = _lib.mgpu_options_from_env()
+            _lib.check(lib.gs_mgpu_create_ex(C.byref(ctx), raw, self.rank, self.world, self.shard_keys, self.capacity, mode,
+                                             self.value_bytes, C.byref(mopts)), "gs_mgpu_create_ex")
         self._ctx = ctx
         if self.always_exchange:
             _lib.check(lib.gs_mgpu_set_force_exchange(ctx, 1), "gs_mgpu_set_force_exchange")

@@ -79,6 +79,34 @@ int gs_last_hip_error(void); /* hipError_t of the last failing HIP call on this 
 gs_status gs_onesweep_create(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes);
 gs_status gs_onesweep_destroy(gs_onesweep* h);
 
+/* Everything that can be chosen about a sorter, in one place (the analogue of the reference's GPUSortingConfig + DeviceInfo,
+ * GPUSortingD3D12/GPUSorting.h:40-86: mode / order / key type / payload type travel with the calls here; what is left are the
+ * algorithm switches below).  The library itself reads NO environment variables: gs_onesweep_create uses the defaults;
+ * harnesses that want GPUSORT_* variables (gpusorting_amd/onesweep.py, tools/) translate them into this struct.
+ * Fill it with gs_onesweep_options_default() first; struct_size lets the struct grow. */
+typedef struct gs_onesweep_options {
+    uint32_t struct_size;            /* sizeof(gs_onesweep_options) */
+    uint32_t shape_threads;          /* tile shape, threads x keys per thread; 0 x 0 (default) = the library picks by size and mode */
+    uint32_t shape_keys_per_thread;
+    int32_t rank_mode;               /* -1 (default) probe the device: 1 if its LDS serves same-address lanes in lane order, else 0;
+                                        0 = 64-lane ballot multi-split, 1 = one returning LDS atomic per key */
+    int32_t small_path;              /* 1 (default): n <= 8192 .. 32 768 keys in ONE workgroup; 0: always tiled */
+    int32_t mid_path;                /* 1 (default): up to 2^20 .. 2^22 keys in two launches (MSD pass + bucket sorts) */
+    int32_t skip_passes;             /* 1 (default): identity passes (a constant byte) are dropped in pairs on the device */
+    int32_t position_chains;         /* skewed keys: 1 (default) position-chain plan when the histogram kernel finds the digit
+                                        groups uneven, 0 never, 2 always (tests, tuning) */
+    uint32_t position_chains_min_log2;  /* ... from 2^this + 1 keys up (default 25; 20 .. 30) */
+    int32_t key64_sweeps;            /* 64-bit keys: 1 (default) one histogram sweep plans all eight passes, 2 one sweep per word */
+    int32_t plan;                    /* gs_onesweep_set_plan: 0 (default), 1 local-sort plan, 2 local-sort plan at every size */
+    int32_t first_pass_big;          /* 1 (default): keys-only mid sizes run their first pass on the 16 384-key tile */
+    uint32_t hist_blocks;            /* workgroups of the GlobalHistogram kernel; 0 (default) = one per CU (tuning aid) */
+    uint32_t debug_flags;            /* tuning builds: extra mode bits handed to the kernels (tools/r04_ls_*.py); 0 */
+} gs_onesweep_options;
+void gs_onesweep_options_default(gs_onesweep_options* o);
+/* gs_onesweep_create with explicit options (NULL = defaults).  GS_ERR_ARG for a struct_size this library does not know, a tile
+ * shape it was not built with, or a value out of range. */
+gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes, const gs_onesweep_options* options);
+
 /* Bytes of device memory a handle for max_keys allocates (descriptors + histograms). */
 size_t gs_onesweep_temp_bytes(uint32_t max_keys);
 /* Keys per binning tile of this build (the reference's k_partitionSize = 7680,
@@ -118,7 +146,7 @@ gs_status gs_onesweep_check(gs_onesweep* h, void* stream);
  * sorts (512x32 keys-only and 8-byte values, 1024x16 4-byte values) and 512x16
  * (8192-key tiles) up to 2^23 / 2^24 / 2^25 keys (keys-only / 4-byte / 8-byte values),
  * where it is faster.  512x32, 1024x16 and 512x16 exist for every key and value type
- * (the tuning build libgpusort_tuning.so adds 256x32, 256x16 and 512x20 for uint32 keys).  Env GPUSORT_SHAPE="TxK" sets it at create. */
+ * (the tuning build libgpusort_tuning.so adds 256x32, 256x16 and 512x20 for uint32 keys).  (gs_onesweep_options::shape_threads / shape_keys_per_thread at create.) */
 gs_status gs_onesweep_set_shape(gs_onesweep* h, uint32_t threads, uint32_t keys_per_thread);
 uint32_t gs_onesweep_get_partition_size(gs_onesweep* h);
 /* Ranking algorithm inside a tile: 0 = 64-lane ballot multi-split (the
@@ -138,13 +166,13 @@ gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
  * bits in LDS; a top byte too skewed for that (a bucket above one tile: 8192 / 16 384 / 32 768 keys) is noticed on the device and the first kernel
  * runs the four LSD passes itself (reference size sweep GPUSortingD3D12/Tests.h:392-393,415-416).  Same
  * result either way; 0 sends these sizes through the general path.  Only used while the library picks the tile shape.
- * Default 1; env GPUSORT_MID_PATH=0/1 sets it at create. */
+ * Default 1 (gs_onesweep_options::mid_path at create). */
 gs_status gs_onesweep_set_mid_path(gs_onesweep* h, int on);
 /* A pass whose digit is the same for every key (e.g. the upper bytes of 16-bit keys) is the
  * identity permutation.  The Scan kernel sees that in the histogram and drops such passes in
  * pairs, on the device, with no host round trip (the reference always runs
  * four passes).  Results are identical either way; 0 runs all four passes.  Default 1;
- * env GPUSORT_SKIP_PASSES=0/1 sets it at create. */
+ * (gs_onesweep_options::skip_passes at create). */
 gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
 /* Plan of large keys-only sorts of 32-bit keys (n > 2^25, library-picked shape, rank mode 1).  1: the LOCAL-SORT plan —
  * the reference's GlobalHistogram + Scan + first DigitBinningPass (GPUSortingCUDA/Sort/OneSweep.cu:44-162 and the first of
@@ -252,6 +280,20 @@ gs_status gs_mgpu_get_unique_id(uint8_t id[GS_MGPU_UNIQUE_ID_BYTES]);
  * scratch array per key/value array (max(shard_keys, capacity) elements).  value_bytes 0 / 4 / 8 as gs_onesweep_create. */
 gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
                          uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes);
+/* Options of a sharded-sort context (the library reads no environment variables; gs_mgpu_create uses the defaults). */
+typedef struct gs_mgpu_options {
+    uint32_t struct_size;   /* sizeof(gs_mgpu_options) */
+    int32_t force_exchange; /* 0 (default); 1: a single rank runs partition + exchange too (tests: world == 1 normally just sorts) */
+    int32_t overlap;        /* 1 (default): pairs send their values on a second stream / communicator behind the keys; 0: one group */
+    int32_t alltoallv;      /* 0 (default): grouped ncclSend / ncclRecv; 1: ncclAllToAllv (also switchable later: gs_mgpu_set_alltoallv) */
+    gs_onesweep_options sorter;  /* options of the context's local sorter (gs_mgpu_sorter); struct_size 0 = defaults */
+} gs_mgpu_options;
+void gs_mgpu_options_default(gs_mgpu_options* o);
+gs_status gs_mgpu_create_ex(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
+                            uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes, const gs_mgpu_options* options);
+/* The bucket exchange of the RCCL transport: 0 grouped ncclSend / ncclRecv, 1 ncclAllToAllv.  Every rank must choose alike.
+ * Takes effect from the next gs_onesweep_sort_sharded (a harness can time both on one context). */
+gs_status gs_mgpu_set_alltoallv(gs_mgpu* ctx, int on);
 gs_status gs_mgpu_destroy(gs_mgpu* ctx);
 /* The sorted array is the concatenation over ranks of what each rank gets back.  Collective.  d_keys[0..n) (and
  * d_vals) is this rank's shard (n may be 0; unchanged on return); d_out_keys / d_out_vals are caller-owned buffers
@@ -259,8 +301,8 @@ gs_status gs_mgpu_destroy(gs_mgpu* ctx);
  * (received order = source rank, source position).  Asynchronous on `stream` except for ONE wait on a few dozen
  * words (per-peer counts: RCCL's send/recv take them as host integers).  Pairs: the values travel on a second stream and (RCCL)
  * a second communicator behind the keys, and the local sort's GlobalHistogram + Scan run on the received keys meanwhile;
- * GPUSORT_MGPU_OVERLAP=0 keeps keys and values in one group, GPUSORT_MGPU_ALLTOALLV=1 uses ncclAllToAllv instead of grouped
- * send / recv (both read at gs_mgpu_create).  GS_ERR_SIZE on EVERY rank if a bucket does not fit `capacity` even at
+ * gs_mgpu_options::overlap = 0 keeps keys and values in one group, ::alltoallv = 1 / gs_mgpu_set_alltoallv uses ncclAllToAllv
+ * instead of grouped send / recv.  GS_ERR_SIZE on EVERY rank if a bucket does not fit `capacity` even at
  * 12-bit-prefix granularity; GS_ERR_COMM on every rank if some rank failed before the histogram gather (see gs_mgpu_check for
  * failures after it).  ARGUMENT errors (GS_ERR_ARG / GS_ERR_SIZE / GS_ERR_MODE: null or misaligned pointers, n > shard_keys, a
  * key type other than the three 32-bit ones) are returned BEFORE the first collective, on the calling rank only: like the
@@ -300,6 +342,8 @@ typedef struct gs_mgpu_transport {
                     const uint32_t* send_counts, const uint32_t* send_displs, const uint32_t* recv_counts,
                     const uint32_t* recv_displs, void* stream);
 } gs_mgpu_transport;
+gs_status gs_mgpu_create_with_transport_ex(gs_mgpu** out, const gs_mgpu_transport* transport, uint32_t rank, uint32_t world,
+                                           uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes, const gs_mgpu_options* options);
 gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* transport, uint32_t rank, uint32_t world,
                                         uint32_t shard_keys, uint32_t capacity, gs_mode mode, uint32_t value_bytes);
 /* The plan as a host function (same rule as the device kernel; CPU tests, other transports): table[src * nbins + b] =

@@ -9,7 +9,7 @@
 //   --mode threads  one process, one THREAD per GPU (the ncclCommInitAll model: ranks share an address space; the id is
 //                   passed in memory; every thread calls gs_mgpu_create = ncclCommInitRank concurrently)
 //   --one-device    every rank on device 0 with world = 1 each is NOT a multi-rank run; with --gpus 1 the exchange path is
-//                   forced (GPUSORT_MGPU_FORCE_EXCHANGE) so that the whole pipeline runs on a one-GPU box
+//                   forced (gs_mgpu_set_force_exchange) so that the whole pipeline runs on a one-GPU box
 // Every rank generates its shard with the library's InitRandom (seed 10 + i + 1000 * rank: bench.py's convention), sorts K
 // times (weak scaling: 2^L keys per GPU), checks its bucket (sorted; sizes add up; bucket borders ascend across ranks) and
 // reports its phase times; rank 0 prints ONE JSON line: GKeys/s of the whole job (slowest rank), per-phase ms (max over
@@ -188,7 +188,6 @@ int main(int argc, char** argv) {
         fprintf(stderr, "bad arguments\n");
         return 2;
     }
-    if (o.gpus == 1) setenv("GPUSORT_MGPU_FORCE_EXCHANGE", "1", 1);
     std::vector<RankResult> res(o.gpus);
     std::vector<int> rc(o.gpus, 0);
     if (o.threads) {
