@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--more-steps", type=int, default=5, help="timed sorts per entry of the 'more' block")
     ap.add_argument("--dry-backend", type=str, default="", help="rehearsal of the N>1 code path on a one-GPU box: 'gloo' = "
                     "every rank on cuda:0, collectives over gloo (host-staged); never used for reported numbers")
+    ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling — 2^log2-keys keys IN TOTAL, split evenly over the GPUs "
+                    "(SURVEY.md 8d cfg 4; default: weak scaling, 2^log2-keys per GPU)")
     ap.add_argument("--cpu-log2", type=int, default=28, help="keys of the host-sort baseline sample (default: the workload itself)")
     return ap.parse_args()
 
@@ -81,6 +83,8 @@ def cpu_baseline(log2n: int):
     dt1 = time.perf_counter() - t0
     return {
         "value": n / dt / 1e9, "unit": "GKeys/s", "cores": used if threads >= 2 else 1, "kind": "port",
+        "stated_baseline": "value / cores above = host std::sort on the box's own cores (north_star): chunked std::sort + merge tree on "
+                           "`cores` threads; single_thread_std_sort below = one plain std::sort call on one core",
         "sample": f"2^{log2n} uint32 keys (InitRandom seed 10, preset 1), chunked std::sort + merge tree on {used} "
                   f"of {threads} hw threads, {dt:.2f} s",
         "single_thread_std_sort": {"value": n1 / dt1 / 1e9, "unit": "GKeys/s", "sample": f"2^{min(log2n, 26)} keys, {dt1:.2f} s"},
@@ -139,8 +143,32 @@ def box_floor(n):
         torch.cuda.synchronize()
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
 
+    def best_of(code, reps=4):
+        """one calibration kernel of the tuning build (threads = 0, kpt = code), best of `reps`"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e30
+        for _ in range(reps + 1):
+            e0.record()
+            if lib.gs_debug_copy_floor(a.data_ptr(), b.data_ptr(), n, 0, code, sp) != 0:
+                return None
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
     seq()
     runs = [seq() for _ in range(4)]
+    # what the box streams at BEST (VERDICT r3 item 2a: the floor as a fact, against the guide's 6.29 TB/s copy): read with four nt loads
+    # in flight, copy as a one-shot grid with four nt loads in flight, copy with four plain loads in flight at one workgroup per CU,
+    # hipMemcpyAsync D2D
+    best = {"read_x4_nt_2wg_per_cu_ms": best_of(4), "copy_x4_nt_one_shot_ms": best_of(5), "copy_x4_1wg_per_cu_ms": best_of(6),
+            "hipMemcpyAsync_d2d_ms": best_of(7)}
+    copies = [v for k, v in best.items() if k != "read_x4_nt_2wg_per_cu_ms" and v]
+    if copies:
+        best["best_copy_GBps"] = 8.0 * n / min(copies) / 1e6
+        best["best_copy_vs_guide_6290_GBps"] = best["best_copy_GBps"] / 6290.0
+    if best["read_x4_nt_2wg_per_cu_ms"]:
+        best["best_read_GBps"] = 4.0 * n / best["read_x4_nt_2wg_per_cu_ms"] / 1e6
     read_ms = min(r[0] for r in runs)
     first_copy = min(r[1] for r in runs)
     steady = sorted(sum(r[3:6]) / 3.0 for r in runs)[len(runs) // 2]
@@ -149,6 +177,7 @@ def box_floor(n):
         "read_only_sweep_ms": read_ms, "read_GBps": 4.0 * n / read_ms / 1e6,
         "tile_copy_ms_first_after_read": first_copy, "tile_copy_ms_steady": steady, "tile_copy_GBps_steady": 8.0 * n / steady / 1e6,
         "floor_ms": floor_ms, "floor_GKeys_per_s": n / floor_ms / 1e6,
+        "streaming_best": best,
         "how": "libgpusort_tuning.so gs_debug_copy_floor: 16-byte grid-stride read sweep; 512x32 tile copy (wave-striped dword loads, LDS "
                "round trip, coalesced dword stores, sequential output); floor = read + first copy + 3 x steady-state copy, HIP events, "
                "best / median of 4 sequences, this process, this box",
@@ -359,6 +388,9 @@ def main():
     from gpusorting_amd.sharded import ShardedOneSweep
 
     n = 1 << args.log2_keys
+    strong = args.strong and world > 1
+    if strong:
+        n = max(n // world, 1)  # keys per GPU: the total stays 2^log2-keys
     K, W = args.steps, args.warmup
     pairs = args.pairs != 0
     vdt = torch.int32 if args.pairs == 4 else torch.int64
@@ -436,6 +468,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1, C-ABI pipeline over RCCL: the same steps with the OTHER bucket-exchange call, timed the same way, so that one run
+    # records both (north_star names ncclAllToAllv; the default is grouped ncclSend / ncclRecv) ----
+    exchange_ab = None
+    if dist is not None and not dry and sharded._ctx and "FALLBACK" not in pipeline:
+        try:
+            reps = min(K, 5)
+            sharded.set_alltoallv(True)
+            for i in range(min(W, 1)):
+                step(i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(reps):
+                step(i)
+            fence()
+            e2 = time.perf_counter() - t1
+            t = torch.tensor([e2], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_ab = {"send_recv_ms_per_step": elapsed / K * 1e3, "alltoallv_ms_per_step": float(t.item()) / reps * 1e3,
+                           "alltoallv_steps": reps, "timed_line_uses": "send_recv"}
+            sharded.set_alltoallv(False)
+            last = step(0)  # (the correctness check below looks at a default-mode step)
+            fence()
+        except Exception as e:  # noqa: BLE001
+            exchange_ab = {"error": str(e)}
+
     # ---- correctness of the last step (outside the timed region) ----
     sorter.check()
     out_k, out_v, out_n = last
@@ -479,6 +536,7 @@ def main():
             "xgmi_link_peak_GBps": link_peak, "links_used_per_rank": world - 1,
             "frac_of_link_peak": per_rank_gbs / max(world - 1, 1) / link_peak,
             "split": sharded.last_split,
+            "exchange_call_ab": exchange_ab,
         }
 
     # ---- per-kernel HIP-event profile of the local 4-pass sort (dominant kernel roofline) ----
@@ -523,13 +581,15 @@ def main():
     ms_per_step = elapsed / K * 1e3
     out = {
         "metric": baseline_metric(), "value": value, "unit": "GKeys/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u32" if not pairs else f"u32 keys + u{8 * args.pairs} values", "data": "synthetic" if not dry else "synthetic (REHEARSAL: ranks share one GPU, gloo; not a measurement)",
         "config": {
             "workload": (f"2^{args.log2_keys} uniform-random uint32 {'pairs' if pairs else 'keys-only'} OneSweep, 1 MI355X "
                          f"(BASELINE configs[{2 if args.pairs == 4 else 4 if args.pairs == 8 else 1}])") if world == 1 else
                         (f"2^{args.log2_keys} uint32 keys per GPU x {world} GPUs: MSD split + RCCL bucket exchange + per-GPU "
-                         f"OneSweep (BASELINE configs[3] shape, weak scaling)"),
+                         f"OneSweep (BASELINE configs[3] shape, weak scaling)") if not strong else
+                        (f"2^{args.log2_keys} uint32 keys in total over {world} GPUs ({n} per GPU): MSD split + RCCL bucket exchange + "
+                         f"per-GPU OneSweep (SURVEY 8d cfg 4, strong scaling)"),
             "timed_region": "whole sort per step: GlobalHistogram (incl. the state clear) + Scan + 4 DigitBinningPass"
                             + ("" if world == 1 else ", after the top-byte split + bucket exchange of the step (all inside the timed region)"),
             "keys_per_gpu": n, "entropy_preset": args.entropy + 1, "generator": "InitRandom seed 10+i (+1000*rank)",

@@ -371,9 +371,15 @@ void launch_small(hipStream_t s, uint32_t* keys, void* vals, uint32_t n, uint32_
     {launch_small<T, K, VB, 0, R>, launch_small<T, K, VB, 1, R>, launch_small<T, K, VB, 2, R>, launch_small<T, K, VB, 3, R>, \
      launch_small<T, K, VB, 4, R>, launch_small<T, K, VB, 5, R>}
 #define GS_SMALL_NONE {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
-// [size class][rank mode][vb index][key type]; 64-bit keys: the 8192-slot class only
+// [size class][rank mode][vb index][key type]; 64-bit keys: the classes up to 8192 slots.  The two smallest classes (256 x 4 and
+// 256 x 8 slots) exist because a sort of 2^10 keys in the 8192-slot shape pays for 8192 slots in every pass: 10.5 us against
+// 8.1 (profiles/r04_small_shapes.txt; the reference's size sweep starts there, GPUSortingD3D12/Tests.h:392-393,415-416)
 #ifndef GS_MINIMAL
-const SmallLauncher g_small[3][2][3][6] = {
+const SmallLauncher g_small[5][2][3][6] = {
+    {{GS_SMALL_ROW64(256, 4, 0, 0), GS_SMALL_ROW64(256, 4, 4, 0), GS_SMALL_ROW64(256, 4, 8, 0)},
+     {GS_SMALL_ROW64(256, 4, 0, 1), GS_SMALL_ROW64(256, 4, 4, 1), GS_SMALL_ROW64(256, 4, 8, 1)}},
+    {{GS_SMALL_ROW64(256, 8, 0, 0), GS_SMALL_ROW64(256, 8, 4, 0), GS_SMALL_ROW64(256, 8, 8, 0)},
+     {GS_SMALL_ROW64(256, 8, 0, 1), GS_SMALL_ROW64(256, 8, 4, 1), GS_SMALL_ROW64(256, 8, 8, 1)}},
     {{GS_SMALL_ROW64(512, 16, 0, 0), GS_SMALL_ROW64(512, 16, 4, 0), GS_SMALL_ROW64(512, 16, 8, 0)},
      {GS_SMALL_ROW64(512, 16, 0, 1), GS_SMALL_ROW64(512, 16, 4, 1), GS_SMALL_ROW64(512, 16, 8, 1)}},
     {{GS_SMALL_ROW(1024, 16, 0, 0), GS_SMALL_ROW(1024, 16, 4, 0), GS_SMALL_NONE},
@@ -386,8 +392,8 @@ inline SmallLauncher small_launcher(uint32_t n, int rank_mode, uint32_t vb, gs_k
 #ifdef GS_MINIMAL
     return nullptr;
 #else
-    const int cls = n <= 8192 ? 0 : n <= 16384 ? 1 : n <= 32768 ? 2 : 3;
-    return cls < 3 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
+    const int cls = n <= 1024 ? 0 : n <= 2048 ? 1 : n <= 8192 ? 2 : n <= 16384 ? 3 : n <= 32768 ? 4 : 5;
+    return cls < 5 ? g_small[cls][rank_mode][vb_index(vb)][kt] : nullptr;  // nullptr: no single-tile kernel for this case
 #endif
 }
 
@@ -864,7 +870,14 @@ gs_status gs_debug_copy_floor(const void* d_in, void* d_out, uint32_t n, uint32_
         if (kpt == 0) hipLaunchKernelGGL(gs::copy_x4_kernel<0>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
         else if (kpt == 1) hipLaunchKernelGGL(gs::copy_x4_kernel<1>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
         else if (kpt == 2) hipLaunchKernelGGL(gs::copy_x4_kernel<2>, dim3(grid), dim3(256), 0, s, vi, vo, nvec);
-        else hipLaunchKernelGGL(gs::read_x4_kernel, dim3(grid), dim3(256), 0, s, vi, out, nvec);
+        else if (kpt == 3) hipLaunchKernelGGL(gs::read_x4_kernel, dim3(grid), dim3(256), 0, s, vi, out, nvec);
+        // round 4: the best shapes tools/r04_probe.hip found — 4: read, four nt loads in flight, two workgroups per CU; 5: copy, four nt
+        // loads in flight, one-shot grid of n / 8192 workgroups; 6: copy, four plain loads in flight, one workgroup per CU; 7: hipMemcpyAsync
+        else if (kpt == 4) hipLaunchKernelGGL((gs::read_xu_kernel<4, true>), dim3(256 * 2), dim3(256), 0, s, vi, out, (size_t)nvec);
+        else if (kpt == 5) hipLaunchKernelGGL((gs::copy_xu_kernel<4, true>), dim3(nvec / (256 * 4) / 2 ? nvec / (256 * 4) / 2 : 1), dim3(256), 0, s, vi, vo, (size_t)nvec);
+        else if (kpt == 6) hipLaunchKernelGGL((gs::copy_xu_kernel<4, false>), dim3(256), dim3(256), 0, s, vi, vo, (size_t)nvec);
+        else if (kpt == 7) GS_HIP(hipMemcpyAsync(d_out, d_in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        else return GS_ERR_ARG;
     } else return GS_ERR_ARG;
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -165,7 +165,13 @@ constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): plan epoch, route flag, bucket table, per-tile
 // claim / flag words, two count tables of MID_MAX_TILES rows
-constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
+// HSUBX: what the counting passes of a position-chain sort add their tables to — HSUB_COPIES copies of CNEXT per pass, one per XCD
+// (workgroup b adds to copy b % 8), and one arrival counter per pass; the last workgroup of a pass to arrive sums the copies into
+// CNEXT.  (Round 3 added straight into CNEXT: 512 workgroups x ~3000 atomics on the SAME 4096 words.)
+constexpr uint32_t HSUB_COPIES = 8;
+constexpr uint32_t SLAB_HSUBX = SLAB_HSUB + 4 * HSUB_STRIDE;
+constexpr uint32_t HSUBX_DONE = 4 * HSUB_COPIES * HSUB_STRIDE;  // [pass] arrival counters, one 128-byte line each
+constexpr uint32_t SLAB_MID = SLAB_HSUBX + HSUBX_DONE + 4 * 32;
 constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
 // LS: what the local-sort plan (ls_kernels.hpp) keeps beside CNEXT: digit-0 totals, OR / AND of the keys, its first kernel's
 // arrival counter, the plan flags and the gather pass's unit geometry
@@ -1703,7 +1709,7 @@ __device__ __forceinline__ void binning_body(
     if constexpr (POS == 1) {
         // hand the counts to the next pass that runs: CNEXT[that pass][segment][digit] += this workgroup's table
         const uint32_t ns = uni(info[I_NEXT_SHIFT]);
-        if ((mode & 2u) && ns != 0xffffffffu) {
+        if ((mode & 2u) && ns != 0xffffffffu && !(uni(info[PASS_FLAGS]) & PF_SKIP)) {
             __syncthreads();
             const uint32_t left_out = uni(s_pos[4]);
             if (left_out < RADIX) {  // the digit count_next skipped: keys written to the segment minus everything that was counted
@@ -1716,9 +1722,29 @@ __device__ __forceinline__ void binning_body(
                 __syncthreads();
             }
             uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
+            // this XCD's copy of the table (blockIdx % 8 is the XCD the workgroup runs on — for speed only: any copy is right)
+            uint32_t* hsubx = hsub + 4 * HSUB_STRIDE;
+            uint32_t* cn_copy = hsubx + ((size_t)(ns >> 3) * HSUB_COPIES + (blockIdx.x & (HSUB_COPIES - 1u))) * HSUB_STRIDE;
             for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
                 const uint32_t v = s_cnt[i];
-                if (v != 0u) atomicAdd(&cn_out[i], v);
+                if (v != 0u) atomicAdd(&cn_copy[i], v);
+            }
+            // arrival: the last workgroup of the pass sums the copies into CNEXT (every workgroup of the launch comes through here, with
+            // or without tiles; one lane's release behind the barrier)
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_pos[6] = atomicAdd(&hsubx[HSUBX_DONE + (ns >> 3) * 32u], 1u);
+            }
+            __syncthreads();
+            if (uni(s_pos[6]) == gridDim.x - 1u) {
+                for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < HSUB_COPIES; ++c) sum += ld_agent(&hsubx[((size_t)(ns >> 3) * HSUB_COPIES + c) * HSUB_STRIDE + i]);
+                    cn_out[i] = sum;
+                }
             }
         }
     }
@@ -2045,6 +2071,32 @@ __global__ __launch_bounds__(256) void copy_x4_kernel(const u32x4* in, u32x4* ou
         u32x4 v;
         if constexpr (MODE >= 1) v = __builtin_nontemporal_load(in + i); else v = in[i];
         if constexpr (MODE >= 2) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+    }
+}
+// The same with U 16-byte loads in flight per thread (round 4: what the box streams at best — tools/r04_probe.hip found the read
+// sweep at 7.1 TB/s with four non-temporal loads in flight and two workgroups per CU, the copy at 6.0 TB/s as a one-shot grid)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void read_xu_kernel(const u32x4* __restrict__ in, uint32_t* sink, size_t nvec) {
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i + (U - 1) * 256 < nvec; i += stride) {
+        u32x4 t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = NT ? __builtin_nontemporal_load(in + i + u * 256) : in[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= t[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+template <int U, bool NTL>
+__global__ __launch_bounds__(256) void copy_xu_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t nvec) {
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i + (U - 1) * 256 < nvec; i += stride) {
+        u32x4 t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = NTL ? __builtin_nontemporal_load(in + i + u * 256) : in[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[i + u * 256] = t[u];
     }
 }
 __global__ __launch_bounds__(256) void read_x4_kernel(const u32x4* in, uint32_t* sink, uint32_t nvec) {

@@ -263,6 +263,12 @@ class ShardedOneSweep:
         """Test hook: this rank's next sort fails on its own (1: before the histogram gather, 2: after the plan)."""
         _lib.check(_lib.load().gs_mgpu_debug_fail(self._ctx, int(where)), "gs_mgpu_debug_fail")
 
+    def set_alltoallv(self, on: bool) -> None:
+        """The RCCL transport's bucket exchange: ncclAllToAllv (True) or grouped ncclSend / ncclRecv (False, default).  Every rank
+        must choose alike; takes effect from the next sort."""
+        if self._ctx:
+            _lib.check(_lib.load().gs_mgpu_set_alltoallv(self._ctx, 1 if on else 0), "gs_mgpu_set_alltoallv")
+
     def profile(self) -> dict:
         """Phase times (ms) and off-rank bytes of the last native sort on this rank."""
         ms = (C.c_float * 4)()

@@ -148,3 +148,62 @@ def test_a_rank_that_fails_alone_does_not_strand_its_peers(gpu, where, pairs):
         assert healthy == ["sort-ok", f"check-status-{_lib.GS_ERR_COMM}"], got
         assert failing[0] == f"sort-status-{_lib.GS_ERR_HIP}", got
     assert got[0][2] and got[1][2], got   # the follow-up call on the same contexts is exact in size and sorted
+
+
+# ---- the REAL transport: RCCL over xGMI, one GPU per rank.  Lights up by itself on a box with two GPUs or more -----------------
+def _rccl_worker(rank, world, port, shard, pairs, alltoallv, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    sys.path.insert(0, ROOT)
+    import gpusorting_amd as g
+    from gpusorting_amd.sharded import ShardedOneSweep
+    keys = torch.empty(shard, dtype=torch.int32, device="cuda")
+    g.init_random(keys, 10 + 1000 * rank, 0)
+    vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
+    k0 = keys.cpu().numpy().view(np.uint32).copy()
+    v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
+    s = ShardedOneSweep(shard, pairs=pairs, value_bytes=4)   # gs_mgpu_create_ex: ncclCommInitRank (+ ncclCommSplit for the values)
+    s.set_alltoallv(alltoallv)
+    outs = []
+    for rep in range(2):                                     # the context's second call as well
+        bk, bv, nb = s.sort(keys, values=vals)
+        torch.cuda.synchronize()
+        s.check()
+        outs.append((bk[:nb].cpu().numpy().view(np.uint32).copy(), None if bv is None else bv[:nb].cpu().numpy().view(np.uint32).copy()))
+    q.put((rank, k0, v0, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+@pytest.mark.parametrize("alltoallv", [False, True])
+def test_sharded_sort_over_rccl_one_gpu_per_rank(gpu, pairs, alltoallv):
+    """the RCCL exchange (grouped ncclSend / ncclRecv and ncclAllToAllv), the values' second communicator and
+    stream, and the closing status gather with a real peer.  Needs two GPUs: skipped on the one-GPU boxes of this pool."""
+    import torch
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device (the gloo-staged tests above cover the pipeline)")
+    shard = (1 << 22) + 12345
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, shard, pairs, alltoallv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([x[1] for x in got])
+    perm = np.argsort(all_keys, kind="stable")
+    for rep in range(2):
+        out_keys = np.concatenate([x[3][rep][0] for x in got])
+        np.testing.assert_array_equal(out_keys, all_keys[perm])
+        if pairs:
+            all_vals = np.concatenate([x[2] for x in got])
+            np.testing.assert_array_equal(np.concatenate([x[3][rep][1] for x in got]), all_vals[perm])
