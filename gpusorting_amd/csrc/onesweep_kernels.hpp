@@ -165,13 +165,7 @@ constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // MID: scratch of the two-launch sort of mid-size inputs (mid_kernels.hpp): plan epoch, route flag, bucket table, per-tile
 // claim / flag words, two count tables of MID_MAX_TILES rows
-// HSUBX: what the counting passes of a position-chain sort add their tables to — HSUB_COPIES copies of CNEXT per pass, one per XCD
-// (workgroup b adds to copy b % 8), and one arrival counter per pass; the last workgroup of a pass to arrive sums the copies into
-// CNEXT.  (Round 3 added straight into CNEXT: 512 workgroups x ~3000 atomics on the SAME 4096 words.)
-constexpr uint32_t HSUB_COPIES = 8;
-constexpr uint32_t SLAB_HSUBX = SLAB_HSUB + 4 * HSUB_STRIDE;
-constexpr uint32_t HSUBX_DONE = 4 * HSUB_COPIES * HSUB_STRIDE;  // [pass] arrival counters, one 128-byte line each
-constexpr uint32_t SLAB_MID = SLAB_HSUBX + HSUBX_DONE + 4 * 32;
+constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
 constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
 // LS: what the local-sort plan (ls_kernels.hpp) keeps beside CNEXT: digit-0 totals, OR / AND of the keys, its first kernel's
 // arrival counter, the plan flags and the gather pass's unit geometry
@@ -645,17 +639,26 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
         for (uint32_t i = tid; i < bins / 4u; i += GHIST_THREADS)
             reinterpret_cast<uint4*>(mine)[i] = reinterpret_cast<const uint4*>(s_h)[i];
     }
-    // (measured: accumulating the OR / AND of all keys here, to drop constant bytes in position-chain sorts too, cost 0.08 ms)
     if (tid == 0 && joint_off) atomicOr(&hist[HIST_TABLE_WORDS + HX_SKEW], 1u);
-    if (allow_pos) {  // (only a sort that may end up on position chains needs them: two atomics per wave)
+    if (allow_pos) {
+        // (only a sort that may end up on position chains needs them.  ONE pair of atomics per workgroup: same-address device atomics
+        //  run at ~100 per microsecond — a pair per wave, 8192 of them, cost this kernel 0.075 ms, profiles/r04_hist_orand_atomics.txt)
 #pragma unroll
         for (int dd = 32; dd > 0; dd >>= 1) {
             k_or |= __shfl_xor(k_or, dd, 64);
             k_nand |= __shfl_xor(k_nand, dd, 64);
         }
+        __syncthreads();  // (s_h is stored: its first words serve as scratch)
+        if (tid < 2) s_h[tid] = 0;
+        __syncthreads();
         if (lane == 0) {
-            atomicOr(&hist[HIST_TABLE_WORDS + HX_OR], k_or);
-            atomicOr(&hist[HIST_TABLE_WORDS + HX_NAND], k_nand);
+            atomicOr(&s_h[0], k_or);
+            atomicOr(&s_h[1], k_nand);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicOr(&hist[HIST_TABLE_WORDS + HX_OR], s_h[0]);
+            atomicOr(&hist[HIST_TABLE_WORDS + HX_NAND], s_h[1]);
         }
     }
     GS_HIST_STAMP(6);
@@ -1722,29 +1725,13 @@ __device__ __forceinline__ void binning_body(
                 __syncthreads();
             }
             uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
-            // this XCD's copy of the table (blockIdx % 8 is the XCD the workgroup runs on — for speed only: any copy is right)
-            uint32_t* hsubx = hsub + 4 * HSUB_STRIDE;
-            uint32_t* cn_copy = hsubx + ((size_t)(ns >> 3) * HSUB_COPIES + (blockIdx.x & (HSUB_COPIES - 1u))) * HSUB_STRIDE;
+            // (Round 4, measured and not kept: one copy of the table per XCD — workgroup b adds to copy b % 8, the last workgroup of the
+            //  pass to arrive sums the copies — against the same-address contention of these atomics: the counting passes got SLOWER,
+            //  0.566 -> 0.588 ms at entropy preset 3, profiles/r04_pos_flush_copies.txt: non-returning atomics do not hold the
+            //  workgroups up, the closing sum by one workgroup does.)
             for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
                 const uint32_t v = s_cnt[i];
-                if (v != 0u) atomicAdd(&cn_copy[i], v);
-            }
-            // arrival: the last workgroup of the pass sums the copies into CNEXT (every workgroup of the launch comes through here, with
-            // or without tiles; one lane's release behind the barrier)
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                s_pos[6] = atomicAdd(&hsubx[HSUBX_DONE + (ns >> 3) * 32u], 1u);
-            }
-            __syncthreads();
-            if (uni(s_pos[6]) == gridDim.x - 1u) {
-                for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (uint32_t c = 0; c < HSUB_COPIES; ++c) sum += ld_agent(&hsubx[((size_t)(ns >> 3) * HSUB_COPIES + c) * HSUB_STRIDE + i]);
-                    cn_out[i] = sum;
-                }
+                if (v != 0u) atomicAdd(&cn_out[i], v);
             }
         }
     }

@@ -104,8 +104,11 @@ class OneSweep:
         if mode == MODE_PAIRS and self.value_bytes == 0:
             self.value_bytes = 4
         h = C.c_void_p()
-        opts = _lib.onesweep_options_from_env(**options)
-        check(self._lib.gs_onesweep_create_ex(C.byref(h), self.max_keys, mode, self.value_bytes, C.byref(opts)), "gs_onesweep_create_ex")
+        if hasattr(self._lib, "gs_onesweep_create_ex"):
+            opts = _lib.onesweep_options_from_env(**options)
+            check(self._lib.gs_onesweep_create_ex(C.byref(h), self.max_keys, mode, self.value_bytes, C.byref(opts)), "gs_onesweep_create_ex")
+        else:  # (A/B runs against a build from before the options struct: GPUSORT_LIB=...)
+            check(self._lib.gs_onesweep_create(C.byref(h), self.max_keys, mode, self.value_bytes), "gs_onesweep_create")
         self._h = h
         self._alt_keys = None
         self._alt_vals = None
