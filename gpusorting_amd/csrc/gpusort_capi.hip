@@ -61,7 +61,13 @@ const BinLauncher g_vr2[2][3] = {{launch_bin<512, 32, 8, 0, 0, 2>, launch_bin<51
 // keys-only sorts of 32-bit keys on the default tile that the Scan kernel may plan on position chains (PF_POS, skewed keys): one
 // launch per pass of the dual kernel — persistent workgroups that run the plain or the position-chain form, as planned.
 // [last pass][key type]
-constexpr uint32_t POS_TILE = 512 * 24;  // tile of the counting position-chain passes (the next-digit table takes 16 KiB of LDS)
+// tile of the counting position-chain passes, as the Scan kernel takes it (bit 31: the plan's last pass runs on it as well).
+// Keys-only: the full tile, counters packed 2 x 16 bit; pairs: 512 x 24 with 32-bit counters — and for 8-byte values in the last
+// pass too (its two staging rounds run 9 % faster on the smaller tile, profiles/r04_pos_packed_counters.txt)
+constexpr uint32_t POS_TILE = 512 * GS_POS_KPT;
+inline uint32_t pos_tile_for(uint32_t vb) {
+    return vb == 0 ? POS_TILE : (512u * GS_POSV_KPT) | ((vb == 8 && GS_POSV8_LAST_SMALL) ? 0x80000000u : 0u);
+}
 template <int KT, bool LAST>
 void launch_dual(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc, uint32_t* counters,
                  const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
@@ -218,7 +224,7 @@ struct gs_onesweep {
     gs_key_type msd_kt;
     uint32_t* pinned;  // 1024 + 8 words of pinned host memory for read-backs
     // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
-    uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride;
+    uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride, last_pos_tile = 0;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
     // local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys from ls_min_keys up
     uint32_t hist_blocks_opt;  // gs_onesweep_options::hist_blocks (0 = the library picks)
@@ -304,14 +310,15 @@ struct PassPlan {
 };
 // shape0_index >= 0: the plan's first pass runs on that (larger) tile shape, the others on shape_index
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
-                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0, int shape0_index = -1) {
+                   uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0, int shape0_index = -1,
+                   uint32_t pos_tile = POS_TILE) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tile0 = shape0_index < 0 ? tile : (uint32_t)g_shapes[shape0_index].threads * g_shapes[shape0_index].kpt;
     const uint32_t tiles = div_up(n, tile < tile0 ? tile : tile0);
     // every chain: its tiles (+1 partial) + row 0; bit 2 of the plan: the sort may end up on the (smaller) position-chain tiles
-    const uint32_t rows = ((scan_plan & 4u) && POS_TILE < tile ? div_up(n, POS_TILE) : tiles) + 2 * gs::MAXCH + 2;
+    const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + 2 * gs::MAXCH + 2;
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
@@ -339,15 +346,15 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
     if (np > 4)  // 64-bit keys: all eight passes from one sweep
         hipLaunchKernelGGL(gs::scan_kernel<8>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE, tile0);
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, pos_tile, tile0);
     else
         hipLaunchKernelGGL(gs::scan_kernel<4>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
-                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, POS_TILE, tile0);
+                           h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, pos_tile, tile0);
     if (rec) GS_HIP(hipEventRecord(h->ev[3], s));
     plan->grid = div_up(n, tile) + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->grid0 = div_up(n, tile0) + gs::MAXCH + 1;
     plan->desc_stride = desc_stride;
-    h->last_n = n; h->last_tile = tile; h->last_tile0 = tile0; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u;
+    h->last_n = n; h->last_tile = tile; h->last_tile0 = tile0; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u; h->last_pos_tile = pos_tile;
     h->last_desc_stride = desc_stride;
     return GS_OK;
 }
@@ -561,7 +568,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0);
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0, pos_tile_for(vb));
         if (st != GS_OK) return st;
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
         for (uint32_t p = 0; p < NP; ++p) {
@@ -722,7 +729,7 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->pinned = nullptr;
     h->trace_buf = nullptr;
     h->msd_keys = nullptr;
-    h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = 0;
+    h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = h->last_pos_tile = 0;
     h->hist_dirty = false;
     h->ls_plan = 0;  // opt-in until it beats the GlobalHistogram / Scan / 4-pass pipeline on uniform keys (set below once the tables exist)
     h->ls_min_keys = (1u << 25) + 1u;  // (below: the 8192-key tile and the two-launch routes)
@@ -944,7 +951,7 @@ gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream)
     if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) ret = GS_ERR_HIP;
     if (ret == GS_OK) {
         hipLaunchKernelGGL(gs::check_state_kernel, dim3(gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
-                           h->last_tile, 0u, h->last_dyn, d, POS_TILE, h->last_tile0);
+                           h->last_tile, 0u, h->last_dyn, d, h->last_pos_tile, h->last_tile0);
         if (hipMemcpyAsync(report, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             ret = GS_ERR_HIP;

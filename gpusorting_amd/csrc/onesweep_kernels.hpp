@@ -197,6 +197,15 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && S
                          // 4 takes 3 % off its keys-only sort and 6 % off its (u32, u64) pairs, nothing changes elsewhere
                          // (profiles/r03_ab_skew_threshold.txt)
 #endif
+#ifndef GS_POS_KPT
+#define GS_POS_KPT 32  // keys per thread of the counting position-chain passes (512 threads): the full tile, with packed counters
+#endif
+#ifndef GS_POSV_KPT
+#define GS_POSV_KPT 24  // the same for pairs (32-bit counters: packing them costs these passes more than the larger tile returns)
+#endif
+#ifndef GS_POSV8_LAST_SMALL
+#define GS_POSV8_LAST_SMALL 1  // (u32, u64) pairs: the last position-chain pass runs on the smaller tile as well
+#endif
 #ifndef GS_POS_SHARE
 #define GS_POS_SHARE 3u  // a digit group holding more than GS_POS_SHARE / 16 of a workgroup's first 16 384 keys (even: 1 / 16) sends the
                          // sort to the position-chain kernels
@@ -469,31 +478,48 @@ __global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const u
                 atomicAdd(&s_r[(d >> 1) * 32u + (lane & 31u)], 1u << ((d & 1u) * 16u));
             }
 #endif
+            // Skew (Thearling-Smith presets, constant bytes): same-address LDS atomics serialise per lane.  Cheap probe on
+            // the first key of a work item's first chunk: do >= 8 lanes share the first lane's bin?  (On every chunk the
+            // probe cost the uniform case 10 % of the kernel, profiles/r02_ab_hist_variants.txt; skew does not come and go
+            // chunk by chunk.)  The probe runs BEFORE the adds so that a wave that has seen no dominant bin does every add of
+            // the chunk in one basic block: the address arithmetic of one table overlaps the LDS adds of the previous one
+            // (with uniform branches between the tables they could not: profiles/r04_hist_kernel_variants.txt).
+            if (GS_HIST_PROBE && probe) {
+#pragma unroll
+                for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < NQ; ++q)
+                    if (q < np && (JOINT || q == 0)) {
+                        const uint32_t bin0 = bin_of(b[0], bh[0], q, x0);
+                        const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin0);
+                        const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin0 == b0));
+                        if (pc >= GS_HIST_SKEW_LANES) {
+                            skew_mode |= 1u << q;
+                            if (pc >= 24 || sticky[q] == 0xffffffffu) sticky[q] = b0;  // (re)learn the dominant bin
+                        }
+                    }
+            }
+            if (skew_mode == 0u) {  // uniform
+#pragma unroll
+                for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < NQ; ++q)
+                    if (q < np && (JOINT || q == 0)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&s_h[bin_of(b[j], bh[j], q, x0)], 1u);
+                    }
+                return;
+            }
 #pragma unroll
             for (uint32_t q = GS_HIST_REPLICAS ? 1 : 0; q < NQ; ++q) {
                 if (q < np && (JOINT || q == 0)) {
                     uint32_t bin[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bin[j] = bin_of(b[j], bh[j], q, x0);
-                    // Skew (Thearling-Smith presets, constant bytes): same-address LDS atomics serialise
-                    // per lane.  Cheap probe on the first key: do >= 8 lanes share the first lane's bin?
-                    // (only the first chunk of a work item probes: on every chunk the probe cost the uniform case
-                    //  10 % of the kernel, profiles/r02_ab_hist_variants.txt; skew does not come and go chunk by chunk)
-                    uint32_t b0 = 0, pc = 0;
-                    if (probe || (skew_mode & (1u << q))) {
-                        b0 = __builtin_amdgcn_readfirstlane(bin[0]);
-                        pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
-                    }
-                    if (GS_HIST_PROBE && probe && pc >= GS_HIST_SKEW_LANES) {
-                        skew_mode |= 1u << q;
-                        if (pc >= 24 || sticky[q] == 0xffffffffu) sticky[q] = b0;  // (re)learn the dominant bin
-                    }
                     if (skew_mode & (1u << q)) {
                         // lanes holding the remembered dominant bin are counted with ONE add of their
                         // popcount (by their first lane); all other lanes add individually
                         // (measured and not kept: counting those lanes on the scalar unit only — a running popcount,
                         //  added when the guess changes — skewed presets -2 %, uniform +4 %: the cost under skew is the
                         //  conflicts among the OTHER hot bins, profiles/r02_skew_rank_fixed_mode.txt)
+                        const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin[0]);
+                        const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
                         uint32_t hit = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -709,7 +735,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
                                                     uint32_t seg_len0, uint32_t tile_keys,
                                                     uint32_t plan /*bit0 descending, bit1 full 4-pass sort: may skip identity
                                                                     passes, bit2 (with bit1): position chains in every pass allowed*/,
-                                                    uint32_t tile_keys_pos /*tile of the position-chain kernels (bit2)*/,
+                                                    uint32_t tile_keys_pos /*tile of the position-chain kernels (bit2); bit 31: of their last pass (3) as well*/,
                                                     uint32_t tile_keys0 /*tile of the plan's first pass (mid sizes: the first pass runs on the
                                                                           larger tile, its position segments are whole tiles)*/) {
     __shared__ uint32_t s_wtot[2][4];
@@ -837,7 +863,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         uint32_t rows = 0;
         // (PF_POS: the passes that count for a successor run on the smaller tile, the last one on the full-size tile)
         if (lane < MAXCH)
-            rows = chain_tiles(s_start[lane], s_end[lane], (pos && q != 3u) ? tile_keys_pos : (q == 0u ? tile_keys0 : tile_keys)) + 1u;
+            rows = chain_tiles(s_start[lane], s_end[lane], (pos && (q != 3u || (tile_keys_pos >> 31))) ? (tile_keys_pos & 0x7fffffffu) : (q == 0u ? tile_keys0 : tile_keys)) + 1u;
         const uint32_t rincl = wave_inclusive_scan(rows, lane);
         if (lane <= MAXCH) s_rowbase[lane] = rincl - rows;
     }
@@ -903,8 +929,14 @@ struct BinCfg {
     // pass's digit per output position segment while they scatter — table [NCH][256] kept for the workgroup's whole life —
     // and derive the pass's digit starts from the counts of the pass before (256 words + 8)
     // POS = 2: the same without the counting and its table — the last pass of such a sort, on full-size tiles
-    static constexpr int POS_BYTES = POS == 1 ? (NCH * RADIX * 4 + RADIX * 4 + 128) : POS == 2 ? (RADIX * 4 + 32) : 0;
-    static constexpr int LDS_BYTES = STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + POS_BYTES + GS_ABL_COUNT_LDS;
+    // (POS = 1 keeps its counters PACKED, two 16-bit counts per word — the next-digit table 8 KiB, the per-wave rank counters
+    //  4 KiB — so that a full 512 x 32 tile leaves room for a second workgroup on the CU: 79.2 KiB.  Round 3 counted in 32-bit
+    //  words on 512 x 24 tiles and paid 0.08 ms per pass for the smaller tile, profiles/r04_pos_packed_counters.txt.)
+    //  Only where the 32-bit counters do not fit beside a second workgroup: the packed form costs ~2 vector instructions per key.)
+    static constexpr bool PACKED = POS == 1 && STAGE_BYTES + WAVES * RADIX * 4 + 2 * RADIX * 4 + 64 + NCH * RADIX * 4 + RADIX * 4 + 128 > 80 * 1024;
+    static constexpr int WHIST_BYTES = WAVES * RADIX * (PACKED ? 2 : 4);
+    static constexpr int POS_BYTES = POS == 1 ? (NCH * RADIX * (PACKED ? 2 : 4) + RADIX * 4 + 128) : POS == 2 ? (RADIX * 4 + 32) : 0;
+    static constexpr int LDS_BYTES = STAGE_BYTES + WHIST_BYTES + 2 * RADIX * 4 + 64 + POS_BYTES + GS_ABL_COUNT_LDS;
     // residency we ask the register allocator for: as many workgroups per CU as
     // LDS (160 KiB) and the 2048-thread limit admit, so that one workgroup's
     // look-back wait is covered by its neighbours' work
@@ -955,12 +987,13 @@ __device__ __forceinline__ void binning_body(
     static_assert(POS == 0 || PERSIST, "the position-chain forms keep state across their tiles");
     uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_raw);
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_raw + Cfg::STAGE_BYTES);
-    uint32_t* s_dpre = s_whist + WAVES * RADIX;  // tile-local exclusive digit prefix
+    constexpr bool PK = Cfg::PACKED;             // two 16-bit counters per word: per-wave rank counters and next-digit table
+    uint32_t* s_dpre = s_whist + Cfg::WHIST_BYTES / 4;  // tile-local exclusive digit prefix
     uint32_t* s_gbase = s_dpre + RADIX;          // global base of digit run minus s_dpre
     uint32_t* s_misc = s_gbase + RADIX;          // [0] chain, [1] ticket (~0 = none), [4..7] wave totals of the digit scan,
                                                  // [9..14] the pass's flag/plan words
-    uint32_t* s_cnt = s_misc + 16;               // POS: [NCH][256] keys written to position segment x whose next digit is d
-    uint32_t* s_dstart = s_cnt + (POS == 1 ? NCH * RADIX : 0);  // POS: digit starts of this pass (from the counts of the pass before)
+    uint32_t* s_cnt = s_misc + 16;               // POS: [NCH][256] keys written to position segment x whose next digit is d, 16 bits each
+    uint32_t* s_dstart = s_cnt + (POS == 1 ? NCH * RADIX / (PK ? 2 : 1) : 0);  // POS: digit starts of this pass (from the counts of the pass before)
     uint32_t* s_pos = s_dstart + (POS ? RADIX : 0);        // POS: [0] some digit holds > n/16 keys, [2..3] (count << 8 | 255 - digit) max;
                                                            // POS == 1: [4] the next digit this workgroup does NOT count (see count_next), [5] its election, [8..23] keys written per output segment
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -987,7 +1020,7 @@ __device__ __forceinline__ void binning_body(
     const uint32_t* cn_in = hsub + (shift_full >> 3) * HSUB_STRIDE;
     if constexpr (POS != 0) {
         if constexpr (POS == 1) {
-            for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) s_cnt[i] = 0;
+            for (uint32_t i = tid; i < NCH * RADIX / (PK ? 2 : 1); i += THREADS) s_cnt[i] = 0;
             if (tid < 32u && tid >= 4u) s_pos[tid] = tid == 4u ? 0xfffffffeu : 0u;  // [4]: not chosen yet
         }
         pos_derived = shift_full != 0u;  // (the first pass of a PF_POS sort is never dropped: its chains come from the Scan kernel)
@@ -1015,6 +1048,8 @@ __device__ __forceinline__ void binning_body(
             pos_mode = pos_skew ? 255u - (uni(s_pos[2]) & 255u) : 0xffffffffu;
         }
     }
+    // (POS == 1) the digit position this workgroup counts for, ~0: none — the same word every tile reads below as next_shift
+    const uint32_t guard_ns = (POS == 1 && (mode & 2u)) ? uni(info[I_NEXT_SHIFT]) : 0xffffffffu;
     GS_TRACE_SETUP();
     // (measured and not kept, PERSIST: the next tile's ticket drawn while this tile is scattered — +0.5 .. 1 %: a tile claimed
     //  4 us before its workgroup starts on it publishes its counts 4 us late for the tiles behind it,
@@ -1022,7 +1057,31 @@ __device__ __forceinline__ void binning_body(
 #pragma unroll 1
     for (;;) {  // PERSIST: one tile after the other until every chain is claimed; otherwise ONE tile per workgroup
     if constexpr (PERSIST) __syncthreads();  // the last tile's readers of the stage and of s_misc are through
-    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+    if constexpr (POS == 1 && PK) {
+        // Overflow guard of the packed next-digit table: a tile adds at most TILE = 16 384 to a counter, so a counter at or above
+        // 0xC000 goes to CNEXT now (and out of the segment's written-keys total, which the left-out digit is recovered from).
+        // Nobody adds to the table between the barrier above and this tile's scatter.  Rare: a workgroup sees ~32 tiles, and its
+        // most frequent next digit is not counted at all.
+        if (guard_ns != 0xffffffffu) {  // uniform
+            for (uint32_t i = tid; i < NCH * RADIX / 2; i += THREADS) {
+                uint32_t w = s_cnt[i];
+                if (GS_UNLIKELY((w & (w << 1) & 0x80008000u) != 0u)) {
+                    uint32_t* cn_out = hsub + (guard_ns >> 3) * HSUB_STRIDE;
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        const uint32_t v = (w >> (16u * h)) & 0xffffu;
+                        if (v >= 0xC000u) {
+                            atomicAdd(&cn_out[2u * i + h], v);
+                            atomicSub(&s_pos[8u + (i >> 7)], v);
+                            w &= ~(0xffffu << (16u * h));
+                        }
+                    }
+                    s_cnt[i] = w;
+                }
+            }
+        }
+    }
+    for (uint32_t i = tid; i < Cfg::WHIST_BYTES / 4; i += THREADS) s_whist[i] = 0;
     GS_TRACE(0);
     // ---- claim a tile.  Fast path: ONE returning atomic on the ticket counter of
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
@@ -1201,7 +1260,13 @@ __device__ __forceinline__ void binning_body(
 
     // ---- rank every key among the keys of its digit inside this wave ----
     // offp[] holds two 16-bit ranks (later: tile-local positions) per register.
-    uint32_t* whist = s_whist + wave * RADIX;
+    // PK: waves 2k and 2k + 1 share the 256 words of a counter block, one half each (the most a wave counts is 64 x KPT <= 2048
+    // and a stage slot is < TILE <= 65536, so a half never carries into the other).  The half is a property of the WAVE: its shift
+    // and its increment are scalars, and no two digits of one wave meet on a word.
+    // (Measured and not kept: the ranking and staging code once per half, picked by a uniform branch on the wave's parity, so that the
+    //  shift is a compile-time constant — 34 spilled registers and 0.55 -> 0.58 ms per counting pass, profiles/r04_pos_packed_counters.txt.)
+    const uint32_t wsh = PK ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((wave & 1u) * 16u)) : 0u;
+    uint32_t* whist = s_whist + (PK ? wave >> 1 : wave) * RADIX;
     uint32_t offp[KPT / 2];
 #pragma unroll
     for (int i = 0; i < KPT / 2; ++i) offp[i] = 0;
@@ -1235,11 +1300,17 @@ __device__ __forceinline__ void binning_body(
         // where the LDS hands same-address lanes of ONE wave-instruction their
         // results in ascending lane order; gs_selftest_lds_atomic_order() probes
         // exactly that on the device before this path is ever selected.
+      {
+        // one returning LDS add on the wave's counter of digit d
+        auto rank_add = [&](uint32_t d) -> uint32_t {
+            const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return PK ? (r >> wsh) & 0xffffu : r;
+        };
         if (GS_LIKELY((pflags & PF_SKEW) == 0u && full)) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
-                const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t r = rank_add(d);
                 offp[i >> 1] |= r << (16 * (i & 1));
             }
         } else if ((pflags & PF_SKEW) == 0u) {
@@ -1250,7 +1321,7 @@ __device__ __forceinline__ void binning_body(
             for (int i = 0; i < KPT; ++i) {
                 if (my_base + i * 64u < hi) {
                     const uint32_t d = (key[i] >> shift) & 255u;
-                    const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t r = rank_add(d);
                     offp[i >> 1] |= r << (16 * (i & 1));
                 }
             }
@@ -1276,16 +1347,25 @@ __device__ __forceinline__ void binning_body(
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(d == sd);
                     ret[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
                     run += (uint32_t)__popcll(m);
-                    if (d != sd) ret[j] = __hip_atomic_fetch_add(&whist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (PK: the counter's WORD comes back; the wave's half is taken out below, outside the branch — inside, every
+                    //  add waited for its own return before the next one was issued.  The other lanes' ranks go through the same
+                    //  extraction: they are shifted into the half here.)
+                    if constexpr (PK) ret[j] <<= wsh;
+                    if (d != sd) ret[j] = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
 #pragma unroll
                 for (int j = 0; j < SKEW_CHUNK; ++j) {
                     const int i = c + j;
+                    if constexpr (PK) ret[j] = (ret[j] >> wsh) & 0xffffu;
                     if (i & 1) offp[i >> 1] |= ret[j] << 16; else offp[i >> 1] |= ret[j];
                 }
             }
-            if (lane == 0 && sd < RADIX) whist[sd] = run;
+            if (lane == 0 && sd < RADIX) {
+                if constexpr (PK) atomicAdd(&whist[sd], run << wsh);  // (nobody of this wave added to its half; the other half is the neighbour wave's)
+                else whist[sd] = run;
+            }
         }
+      }
     }
     GS_TRACE(2);
     __syncthreads();
@@ -1298,9 +1378,18 @@ __device__ __forceinline__ void binning_body(
         uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = s_whist[w * RADIX + tid];
-            s_whist[w * RADIX + tid] = run;
-            run += c;
+            if constexpr (PK) {  // (one word holds this digit's counts of waves w and w + 1)
+                if ((w & 1) == 0) {
+                    const uint32_t c2 = s_whist[(w >> 1) * RADIX + tid];
+                    const uint32_t c_even = c2 & 0xffffu, c_odd = c2 >> 16;
+                    s_whist[(w >> 1) * RADIX + tid] = run | ((run + c_even) << 16);
+                    run += c_even + c_odd;
+                }
+            } else {
+                const uint32_t c = s_whist[w * RADIX + tid];
+                s_whist[w * RADIX + tid] = run;
+                run += c;
+            }
         }
         // published counts are the tile's REAL keys: without the dummies in front (digit 0) and, where they were
         // ranked at all (ballot ranking, skewed passes), without the dummies behind the segment (digit 255) — the
@@ -1319,7 +1408,10 @@ __device__ __forceinline__ void binning_body(
         dpre = wbase + scan_incl - (tile_total + dummies);  // stage offset of the run (dummies included)
         s_dpre[tid] = dpre;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
+        for (int w = 0; w < WAVES; ++w) {
+            if constexpr (PK) { if ((w & 1) == 0) s_whist[(w >> 1) * RADIX + tid] += dpre * 0x10001u; }  // (both halves stay stage slots: < TILE <= 65536)
+            else s_whist[w * RADIX + tid] += dpre;
+        }
     }
     __syncthreads();
 
@@ -1340,7 +1432,7 @@ __device__ __forceinline__ void binning_body(
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
-            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
+            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + (PK ? (whist[d] >> wsh) & 0xffffu : whist[d]);
             if constexpr (Cfg::FUSED) {
                 stage_pair(lpos, key[i], val[i]);
             } else {
@@ -1356,7 +1448,7 @@ __device__ __forceinline__ void binning_body(
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t d = (key[i] >> shift) & 255u;
-            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + d];
+            const uint32_t lpos = ((offp[i >> 1] >> (16 * (i & 1))) & 0xffffu) + (PK ? (whist[d] >> wsh) & 0xffffu : whist[d]);
             if constexpr (Cfg::FUSED) {
                 if (my_base + i * 64u < hi) stage_pair(lpos, key[i], val[i]);
             } else {
@@ -1523,7 +1615,8 @@ __device__ __forceinline__ void binning_body(
     // at entropy presets 3 / 5 against 0.01 ms for uniform keys, profiles/r03_next_digit_count_cost.txt).
     auto count_next = [&](uint32_t kb, uint32_t o, bool valid) {
         const uint32_t dn = (kb >> (next_shift & 31u)) & 255u;
-        if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 8) + dn], 1u);
+        if constexpr (PK) { if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 7) + (dn >> 1)], 1u << ((dn & 1u) * 16u)); }
+        else { if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 8) + dn], 1u); }
     };
     const bool counting = POS == 1 && next_shift != 0xffffffffu;  // uniform
     if constexpr (POS == 1) {
@@ -1715,6 +1808,36 @@ __device__ __forceinline__ void binning_body(
         if ((mode & 2u) && ns != 0xffffffffu && !(uni(info[PASS_FLAGS]) & PF_SKIP)) {
             __syncthreads();
             const uint32_t left_out = uni(s_pos[4]);
+            uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
+          if constexpr (PK) {
+            if (left_out < RADIX) {  // the digit count_next skipped: keys written to the segment minus everything that was counted
+                const uint32_t lo_word = left_out >> 1, lo_keep = 0xffff0000u >> ((left_out & 1u) * 16u);  // its word in a row, the OTHER half
+                for (uint32_t x = wave; x < NCH; x += WAVES) {
+                    uint32_t sum = 0;
+                    for (uint32_t c = lane; c < RADIX / 2; c += 64u) {
+                        uint32_t w = s_cnt[x * (RADIX / 2) + c];
+                        if (c == lo_word) w &= lo_keep;  // (what the tiles in front of the choice counted for it is part of the total)
+                        sum += (w & 0xffffu) + (w >> 16);
+                    }
+                    sum = wave_reduce_sum(sum);
+                    if (lane == 0) {
+                        const uint32_t v = s_pos[8u + x] - sum;
+                        if (v != 0u) atomicAdd(&cn_out[x * RADIX + left_out], v);
+                        s_cnt[x * (RADIX / 2) + lo_word] &= lo_keep;
+                    }
+                }
+                __syncthreads();
+            }
+            // (Round 4, measured and not kept: one copy of the table per XCD — workgroup b adds to copy b % 8, the last workgroup of the
+            //  pass to arrive sums the copies — against the same-address contention of these atomics: the counting passes got SLOWER,
+            //  0.566 -> 0.588 ms at entropy preset 3, profiles/r04_pos_flush_copies.txt: non-returning atomics do not hold the
+            //  workgroups up, the closing sum by one workgroup does.)
+            for (uint32_t i = tid; i < NCH * RADIX / 2; i += THREADS) {
+                const uint32_t w = s_cnt[i];
+                if ((w & 0xffffu) != 0u) atomicAdd(&cn_out[2u * i], w & 0xffffu);
+                if ((w >> 16) != 0u) atomicAdd(&cn_out[2u * i + 1u], w >> 16);
+            }
+          } else {
             if (left_out < RADIX) {  // the digit count_next skipped: keys written to the segment minus everything that was counted
                 for (uint32_t x = wave; x < NCH; x += WAVES) {
                     uint32_t sum = 0;
@@ -1724,15 +1847,11 @@ __device__ __forceinline__ void binning_body(
                 }
                 __syncthreads();
             }
-            uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
-            // (Round 4, measured and not kept: one copy of the table per XCD — workgroup b adds to copy b % 8, the last workgroup of the
-            //  pass to arrive sums the copies — against the same-address contention of these atomics: the counting passes got SLOWER,
-            //  0.566 -> 0.588 ms at entropy preset 3, profiles/r04_pos_flush_copies.txt: non-returning atomics do not hold the
-            //  workgroups up, the closing sum by one workgroup does.)
             for (uint32_t i = tid; i < NCH * RADIX; i += THREADS) {
                 const uint32_t v = s_cnt[i];
                 if (v != 0u) atomicAdd(&cn_out[i], v);
             }
+          }
         }
     }
 }
@@ -1749,15 +1868,15 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
 
 // Keys-only sorts of 32-bit keys that the Scan kernel MAY plan on position chains (PF_POS, decided on the device from what the
 // histogram kernel saw): ONE launch per pass serves both plans — persistent workgroups, two per CU, that run the plain form of
-// the pass (512 x 32 tiles, chains as planned) or, under PF_POS, its position-chain form: 512 x 24 tiles and the next-digit
-// table while a later pass needs the counts (LAST = false), 512 x 32 tiles without it in the last pass (LAST = true).  (As two
+// the pass (512 x 32 tiles, chains as planned) or, under PF_POS, its position-chain form on the same tiles: with the (packed) next-digit
+// table while a later pass needs the counts (LAST = false), without it in the last pass (LAST = true).  (As two
 // launches per pass, one of them exiting on the flag, every pass paid a second kernel boundary: +0.01 ms, profiles/r03_pos_*.)
 template <int KT, bool LAST>
 __global__ __launch_bounds__(512, 4) void digit_binning_dual_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
     uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
     constexpr int LDS_PLAIN = BinCfg<512, 32, 0, 1, 1, 0>::LDS_BYTES;
-    constexpr int LDS_POS = LAST ? BinCfg<512, 32, 0, 1, 1, 2>::LDS_BYTES : BinCfg<512, 24, 0, 1, 1, 1>::LDS_BYTES;
+    constexpr int LDS_POS = LAST ? BinCfg<512, 32, 0, 1, 1, 2>::LDS_BYTES : BinCfg<512, GS_POS_KPT, 0, 1, 1, 1>::LDS_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_PLAIN > LDS_POS ? LDS_PLAIN : LDS_POS];
     static_assert(sizeof(s_raw) * 2 <= 160 * 1024, "two workgroups per CU");
     if ((__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) == 0) {
@@ -1765,7 +1884,7 @@ __global__ __launch_bounds__(512, 4) void digit_binning_dual_kernel(
     } else if constexpr (LAST) {
         binning_body<512, 32, 0, KT, 1, 1, 2, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
     } else {
-        binning_body<512, 24, 0, KT, 1, 1, 1, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
+        binning_body<512, GS_POS_KPT, 0, KT, 1, 1, 1, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
     }
 }
 
@@ -1778,7 +1897,7 @@ template <int VB, int KT, bool LAST>
 __global__ __launch_bounds__(512, 4) void digit_binning_posv_kernel(
     uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
     uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
-    constexpr int KPT = LAST ? 32 : 24, POS = LAST ? 2 : 1, VR = VB == 8 ? 2 : 1;
+    constexpr int KPT = (LAST && !(VB == 8 && GS_POSV8_LAST_SMALL)) ? 32 : GS_POSV_KPT, POS = LAST ? 2 : 1, VR = VB == 8 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<512, KPT, VB, 1, VR, POS>::LDS_BYTES];
     static_assert(sizeof(s_raw) * 2 <= 160 * 1024, "two workgroups per CU");
     binning_body<512, KPT, VB, KT, 1, VR, POS, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n, shift_full, mode);
@@ -1807,7 +1926,7 @@ __global__ __launch_bounds__(256) void check_state_kernel(const uint32_t* slab, 
     if (dyn && (info[PASS_FLAGS] & PF_SKIP)) return;  // an identity pass that was dropped: nothing ran
     if (chain >= info[I_NCH]) return;
     const uint32_t tiles = chain_tiles(info[I_START + chain], info[I_END + chain],
-                                       ((info[PASS_FLAGS] & PF_POS) && q != 3u) ? tile_keys_pos : (q == 0u ? tile_keys0 : tile_keys));
+                                       ((info[PASS_FLAGS] & PF_POS) && (q != 3u || (tile_keys_pos >> 31))) ? (tile_keys_pos & 0x7fffffffu) : (q == 0u ? tile_keys0 : tile_keys));
     if (tiles == 0) return;
     const uint32_t* rows = slab + SLAB_DESC + (size_t)q * desc_stride + (size_t)info[I_ROW + chain] * RADIX;
     if (tid == 0 && slab[SLAB_COUNTERS + ((p0 + q) * COUNTERS_PER_PASS + chain) * COUNTER_STRIDE] < tiles)

@@ -237,3 +237,28 @@ def test_2pow27_uint64_keys_exact(gpu):
     assert gpu.validate(dk, key_type=gpu.KEY_UINT64) == 0
     assert (int(dk.sum().item()), int((dk % 1000003).sum().item())) == before
     s.close()
+
+
+@pytest.mark.parametrize("values", [2, 3])
+def test_2pow28_few_valued_bytes_packed_counter_guard(gpu, values):
+    """Every byte of the keys takes one of 2 (3) values with equal shares: the histogram kernel finds the digit groups uneven, the
+    sort runs on position chains, and in every counting pass a workgroup's 16-bit next-digit counters would pass 65 535 several
+    times over (2^28 / 512 workgroups = 524 288 keys each, half (a third) of them on a digit that is NOT the one left out) — the
+    overflow guard of the packed table hands them to the global table in between.  Exact against torch.sort."""
+    import torch
+    n = 1 << 28
+    g = torch.Generator(device="cuda"); g.manual_seed(2800 + values)
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for byte, vals in enumerate(((0x11, 0xfe, 0x80), (0x00, 0x7f, 0x3c), (0xa5, 0x5a, 0x01), (0x42, 0x41, 0xff))):
+        pick = torch.randint(0, values, (n,), device="cuda", generator=g)
+        lut = torch.tensor(vals[:values], dtype=torch.int64, device="cuda")
+        keys |= lut[pick] << (8 * byte)
+        del pick
+    dk = keys.to(torch.int32)
+    want = torch.sort(keys).values
+    del keys
+    s = gpu.OneSweep(n)
+    s.sort(dk)
+    s.check()
+    assert bool(torch.equal(dk.to(torch.int64) & 0xFFFFFFFF, want))
+    s.close()
