@@ -503,7 +503,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         uint32_t* eprefix = runs_t + (size_t)gs::RADIX * h->ls_nt_pad;
         uint32_t* stab = eprefix + (size_t)gs::RADIX * h->ls_nt_pad;
         const uint32_t ls_exp = h->debug_flags;  // tuning bits (gs_onesweep_options::debug_flags)
-        g_ls_first[kt](s, grid, ka, kb, runs_t, slices, h->slab, zero_end, n, 2u | ls_exp);
+        // plan bits 8..15 of the first kernel: step of the rotated run layout (1 unless debug_flags bits 8..15 say otherwise; bit 17: off)
+        const uint32_t ls_rot = (ls_exp & 0x20000u) ? 0u : ((ls_exp & 0xff00u) ? (ls_exp & 0xff00u) : 0x100u);
+        g_ls_first[kt](s, grid, ka, kb, runs_t, slices, h->slab, zero_end, n, 2u | (ls_exp & ~0xff00u) | ls_rot);
         const uint32_t tblocks = div_up(nt, 64u);
         hipLaunchKernelGGL(gs::ls_plan_kernel, dim3(tblocks + gs::LS_SLICE_WORDS / 64u), dim3(gs::LS_RED_THREADS), 0, s, runs_t, h->ls_runs, nt, h->ls_nt_pad, tblocks,
                            slices, grid, h->slab, 2u);

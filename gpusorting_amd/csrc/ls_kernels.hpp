@@ -143,7 +143,10 @@ __device__ __forceinline__ void ls_count(const LsTile& T, const uint32_t (&key)[
 // After the ranking barrier: threads k < 128 own the digit pair (2k, 2k + 1).  Turns the per-wave counters into (exclusive prefix
 // over the waves + tile-local start of the digit's run), returns the pair's counts and run starts.
 // Contains two barriers; every thread of the workgroup must call it.
-__device__ __forceinline__ void ls_digit_scan(const LsTile& T, uint32_t tid, uint32_t& c0, uint32_t& c1, uint32_t& dpre0, uint32_t& dpre1) {
+// rot != 0 (uniform; the first kernel): the runs are laid out in the ROTATED digit order rot, rot + 1, .., 255, 0, .., rot - 1 inside the
+// tile (total = the tile's keys) — one more barrier.
+__device__ __forceinline__ void ls_digit_scan(const LsTile& T, uint32_t tid, uint32_t& c0, uint32_t& c1, uint32_t& dpre0, uint32_t& dpre1,
+                                              uint32_t rot = 0u, uint32_t total = 0u) {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t run = 0, incl = 0;
     c0 = c1 = dpre0 = dpre1 = 0;
@@ -164,6 +167,17 @@ __device__ __forceinline__ void ls_digit_scan(const LsTile& T, uint32_t tid, uin
         const uint32_t wbase = wave ? T.s_misc[4] : 0u;
         dpre0 = wbase + incl - (c0 + c1);
         dpre1 = dpre0 + c0;
+        if (rot != 0u && (rot >> 1) == tid) T.s_misc[10] = (rot & 1u) ? dpre1 : dpre0;
+    }
+    if (rot != 0u) {  // uniform
+        __syncthreads();
+        if (tid < RADIX / 2) {
+            const uint32_t first = T.s_misc[10];  // natural start of digit rot's run = keys of the digits below rot
+            dpre0 = 2u * tid >= rot ? dpre0 - first : dpre0 + (total - first);
+            dpre1 = 2u * tid + 1u >= rot ? dpre1 - first : dpre1 + (total - first);
+        }
+    }
+    if (tid < RADIX / 2) {
         const uint32_t add = dpre0 | (dpre1 << 16);  // (start + prefix <= 16 384: no carry between the halves)
 #pragma unroll
         for (uint32_t w = 0; w < LS_WAVES; ++w) T.s_whist[w * (RADIX / 2) + tid] += add;
@@ -321,7 +335,11 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_first_kernel(const uint32_t*
         __syncthreads();
         stamp(3);
         uint32_t c0, c1, dpre0, dpre1;
-        ls_digit_scan(T, tid, c0, c1, dpre0, dpre1);
+        // The tile's runs are laid out in a digit order rotated by the tile's index: the same digit's runs of consecutive tiles then sit
+        // 65 536 - 256 bytes apart (uniform keys) instead of 65 536, and the ~256 run reads of one tile of the gather pass spread over the
+        // memory channels instead of queueing on one or two of them (profiles/r04_ls_rotated_runs.txt).  plan bits 8..15: the step.
+        const uint32_t rot = (t * ((plan >> 8) & 255u)) & 255u;
+        ls_digit_scan(T, tid, c0, c1, dpre0, dpre1, rot, count);
         stamp(4);
         if (tid < RADIX / 2) {  // the run table, one coalesced row per tile: (start inside the tile) << 16 | length
             reinterpret_cast<uint2*>(runs_t + (size_t)t * RADIX)[tid] = uint2{(dpre0 << 16) | c0, (dpre1 << 16) | c1};
