@@ -96,7 +96,7 @@ def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys):
     separate rocprofv3 --pmc passes of this same command and committed under profiles/) — a BORROWED number: it was
     measured by the builder's rocprofv3 runs, not by this run, and the block says so.  None if the committed
     measurement is for another workload/tile shape."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
