@@ -767,78 +767,58 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
         uint32_t p0 = wave * (64u * LS_KPT) + lane;
         asm volatile("" : "+v"(p0));
         if constexpr (GATHER) {
-            // the run list (in the stage) and the run-start bitmap (in the counters' words)
-            uint32_t* s_list = s_stage;
-            uint32_t* s_bits = s_whist;
-            s_bits[tid] = 0;
-            __syncthreads();
-            {
-                const uint32_t* erow = eprefix + (size_t)gd * nt_pad;
-                const uint32_t* rrow = runs + (size_t)gd * nt_pad;
-                uint32_t nrun = 0;  // uniform: runs listed so far
+            // The tile's runs go STRAIGHT INTO THE STAGE, run by run: every thread turns one (E, R) table pair into a list entry
+            // {source index, tile position | length << 16} (the counters' words hold 512 of them), then wave w issues runs w, w + 8, ...
+            // as lane-contiguous direct-to-LDS loads (no address work per key, no registers held by loads in flight), and the keys are
+            // read back in tile order.  (The first form — a run-start bitmap, a rank per key and 32 gathered register loads per thread —
+            // spent 10 700 clocks issuing its loads against 2 000 in the linear pass, profiles/r04_ls_pass_phase_clocks.txt; the probe of
+            // this form: profiles/r04_probe_gather3.txt.)
+            uint2* s_runs = reinterpret_cast<uint2*>(s_whist);
+            static_assert(LS_WH_WORDS >= 2 * LS_THREADS, "the run list lives in the counters' words");
+            const uint32_t* erow = eprefix + (size_t)gd * nt_pad;
+            const uint32_t* rrow = runs + (size_t)gd * nt_pad;
 #pragma unroll 1
-                for (uint32_t e = ge0; e <= ge1; e += LS_THREADS) {
-                    const uint32_t i = e + tid;
-                    uint32_t f = 0, s0 = 0, src = 0;
-                    if (i <= ge1) {
-                        const uint32_t a = erow[i], w = rrow[i];
-                        const uint32_t b = a + (w & 0xffffu);                   // the run's virtual range [a, b)
-                        const uint32_t lo = a > gv0 ? a : gv0, hi = b < gv0 + cnt ? b : gv0 + cnt;
-                        f = hi > lo ? 1u : 0u;
-                        s0 = lo - gv0;                                         // where its keys start in the tile
-                        src = i * LS_TILE + (w >> 16) + (lo - a);              // ... and in the first kernel's output
+            for (uint32_t e = ge0; e <= ge1; e += LS_THREADS) {  // (uniform; one round unless the runs are short: skewed keys)
+                const uint32_t i = e + tid;
+                uint2 ent = {0u, 0u};
+                if (i <= ge1) {
+                    const uint32_t a = erow[i], w = rrow[i];
+                    const uint32_t b = a + (w & 0xffffu);                   // the run's virtual range [a, b)
+                    const uint32_t lo = a > gv0 ? a : gv0, hi = b < gv0 + cnt ? b : gv0 + cnt;
+                    if (hi > lo) ent = uint2{i * LS_TILE + (w >> 16) + (lo - a), (lo - gv0) | ((hi - lo) << 16)};
+                }
+                if (e != ge0) __syncthreads();  // the last round's entries are read
+                s_runs[tid] = ent;
+                __syncthreads();
+                const uint32_t nr = ge1 - e + 1u < LS_THREADS ? ge1 - e + 1u : LS_THREADS;
+#pragma unroll 2
+                for (uint32_t r = wave; r < nr; r += LS_WAVES) {
+                    const uint2 en = s_runs[r];
+                    const uint32_t src = uni(en.x), sl = uni(en.y);
+                    const uint32_t s0 = sl & 0xffffu, len = sl >> 16;
+#pragma unroll 1
+                    for (uint32_t off = 0; off < len; off += 64u) {
+                        if (off + lane < len)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(keys_in + src + off + lane),
+                                                             (__attribute__((address_space(3))) void*)(s_stage + s0 + off), 4, 0, 0);
                     }
-                    const uint32_t jf = wave_inclusive_scan_dpp(f);
-                    if (lane == 63) s_misc[32 + wave] = jf;
-                    __syncthreads();
-                    uint32_t bf = nrun, totf = 0;
-#pragma unroll
-                    for (uint32_t w = 0; w < LS_WAVES; ++w) {
-                        const uint32_t wf = s_misc[32 + w];
-                        if (w < wave) bf += wf;
-                        totf += wf;
-                    }
-                    if (f) {
-                        s_list[bf + jf - 1u] = src - s0;
-                        atomicOr(&s_bits[s0 >> 5], 1u << (s0 & 31u));
-                    }
-                    nrun += totf;
-                    __syncthreads();
                 }
             }
-            stamp(2);  // run list
-            const unsigned long long* s_bits64 = reinterpret_cast<const unsigned long long*>(s_whist);
-            unsigned long long mine = 0;
-            if (lane < LS_KPT) mine = s_bits64[wave * LS_KPT + lane];  // lane i: the run-start bits of the wave's item i
-            uint32_t pc = wave_reduce_sum((uint32_t)__popcll(mine));
-            if (lane == 0) s_misc[40 + wave] = pc;
+            stamp(2);  // run list, loads issued
+            __builtin_amdgcn_s_waitcnt(0);  // (vmcnt(0): this wave's direct loads have landed)
             __syncthreads();
-            uint32_t before = 0;  // uniform: runs that start in front of this wave's 2048 positions
-            for (uint32_t w = 0; w < wave; ++w) before += s_misc[40 + w];
-            before = uni(before);
-            const uint32_t mlo_v = (uint32_t)mine, mhi_v = (uint32_t)(mine >> 32);
-            const uint32_t last = cnt ? cnt - 1u : 0u;
             if (GS_LIKELY(cnt != 0u)) {
-#pragma unroll
-                for (int i = 0; i < (int)LS_KPT; ++i) {
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo_v, i), mhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi_v, i);
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                    const uint32_t self = (uint32_t)((((unsigned long long)mhi << 32) | mlo) >> lane) & 1u;
-                    const uint32_t r = before + below + self - 1u;  // (position 0 of a non-empty tile starts a run)
-                    before += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-                    key[i] = s_list[r];  // (all 32 list reads in flight, then all 32 key loads: one LDS round trip, not 32)
-                }
+                const uint32_t last = cnt - 1u;
 #pragma unroll
                 for (int i = 0; i < (int)LS_KPT; ++i) {
                     const uint32_t p = p0 + i * 64u;
-                    // (positions behind a partial tile read its last key again)
-                    key[i] = to_bits<KT>(keys_in[key[i] + (p < cnt ? p : last)]);
+                    key[i] = to_bits<KT>(s_stage[p < cnt ? p : last]);  // (positions behind a partial tile hold its last key again)
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < (int)LS_KPT; ++i) key[i] = 0xffffffffu;
             }
-            __syncthreads();  // the list and the bitmap are read: stage and counters may be reused
+            __syncthreads();  // the stage and the list are read: stage and counters may be reused
         } else if (GS_LIKELY(full)) {
 #pragma unroll
             for (int i = 0; i < (int)LS_KPT; ++i) key[i] = to_bits<KT>(__builtin_nontemporal_load(keys_in + tile_base + p0 + i * 64u));
