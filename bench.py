@@ -356,9 +356,36 @@ def size_sweep(g, sorts=10):
                     done += nb
             s.check()
             ok = g.validate(ks[-1], vs[-1]) == 0
-            s.close()
             us = total / done * 1e3
-            rows[name].append({"log2_keys": lg, "us_per_sort": round(us, 2), "GKeys_per_s": round(n / us / 1e3, 3), "sorted": bool(ok)})
+            row = {"log2_keys": lg, "us_per_sort": round(us, 2), "GKeys_per_s": round(n / us / 1e3, 3), "sorted": bool(ok)}
+            if lg <= 20:
+                # the same batch captured ONCE into a HIP graph and replayed: what the sorts cost when the host's launch calls are out of
+                # the picture (a sort is pure stream work: nothing synchronous, nothing read back)
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for i in range(nb):
+                            s.sort(ks[i], vs[i], alt_keys=alt, alt_values=valt)
+                    tg, dg = 0.0, 0
+                    for rnd in range(3):
+                        for i in range(nb):
+                            g.init_random(ks[i], 40 + rnd * nb + i, 0, vs[i])
+                        torch.cuda.synchronize()
+                        a.record()
+                        graph.replay()
+                        b.record()
+                        b.synchronize()
+                        if rnd:
+                            tg += a.elapsed_time(b)
+                            dg += nb
+                    s.check()
+                    row["us_per_sort_graph_replay"] = round(tg / dg * 1e3, 2)
+                    row["sorted_graph_replay"] = bool(g.validate(ks[-1], vs[-1]) == 0)
+                    del graph
+                except Exception as e:  # (a capture failure must not take the bench line with it)
+                    row["graph_replay_error"] = str(e)[:120]
+            s.close()
+            rows[name].append(row)
     return rows
 
 
