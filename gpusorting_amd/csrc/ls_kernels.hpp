@@ -9,18 +9,23 @@
 //                     16-byte stores, no descriptors, no look-back — together with a run table R[digit][tile] =
 //                     (start of the digit's run inside the tile, its length).  The array in the virtual order
 //                     (digit 0, tile, position in the run) IS the output of a stable first pass; it is never materialised.
-//   ls_pass_kernel    GATHER form (second pass): a work unit = the runs (d, t0..t1) of ONE digit-0 value in consecutive source
-//                     tiles, sized from the digit's total to fill ~97 % of a tile; units in (digit, tile) order are the virtual
-//                     order, so the chained scan over units (16 chains = 16 groups of digit-0 values) is the stable second
-//                     pass.  Runs are ~64 keys at 4-byte-aligned offsets; read with plain (cached) loads they cost nothing
-//                     over a sequential read (profiles/r04_probe_gather.txt: the XCD's L2 serves the lines two runs share).
-//                     LINEAR form (third and fourth pass): the usual tile over the pass's input.
+//   ls_plan_kernel    transposes the run table to R[digit][tile], sums the workgroups' table slices into CNEXT[1] and the digit-0
+//                     totals, and writes the plan words: chain geometry of the gather pass, whether the two upper passes are identity
+//                     permutations (bytes 2 and 3 constant: dropped as a pair).
+//   ls_runscan_kernel E[digit][tile] = exclusive prefix of a digit's run lengths over the tiles (positions in the virtual order),
+//                     S = the first run every 16 384-key VIRTUAL tile of every digit touches.
+//   ls_pass_kernel    GATHER form (second pass): tile j of digit d = virtual positions [16 384 j, 16 384 (j + 1)) of that digit's keys
+//                     (exact tiles, one partial tile per digit), i.e. ~256 runs of ~64 keys at 4-byte-aligned offsets of consecutive
+//                     source tiles, found through S / E / R and loaded run by run straight into the LDS stage; tiles in
+//                     (digit, tile) order are the virtual order, so the chained scan over them (16 chains = 16 groups of digit-0
+//                     values) is the stable second pass.  LINEAR form (third and fourth pass): the usual tile over the pass's input.
 //   no histogram sweep: every pass counts the NEXT pass's joint table H[next digit][group of this digit] while its keys are in
-//                     registers (16-bit packed LDS counters, flushed to CNEXT with global atomics when the workgroup runs out of
-//                     tiles or a counter nears overflow); the workgroups of the next pass derive digit starts, chain geometry and
-//                     chain seeds from it.  The first kernel also accumulates digit-0 totals and the OR / AND of all keys; its last
-//                     workgroup to finish turns them into the plan: unit geometry of the gather pass, and whether the two
-//                     upper passes are identity permutations (both bytes constant: dropped as a pair).
+//                     registers (16-bit packed LDS counters, flushed into the workgroup's own SLICE in global memory — no atomics —
+//                     when it runs out of tiles or a counter nears overflow); ls_reduce_kernel (ls_plan_kernel behind the first
+//                     kernel) sums the slices, and the workgroups of the next pass derive digit starts, chain geometry and chain
+//                     seeds from the table.
+// Status (profiles/r04_ls_plan_status.txt): bit-exact and SLOWER than the default pipeline (the gather pass pays three dependent
+// global round trips per tile); opt-in through gs_onesweep_options::plan.
 //
 // Descriptors, flags, bounded spins, POISON, fallback recount: as in onesweep_kernels.hpp (same words, same meaning).
 #pragma once
@@ -578,10 +583,9 @@ __global__ __launch_bounds__(1024) void ls_runscan_kernel(const uint32_t* __rest
 // chain's ticket 0).
 // GATHER (pass 1): the input is the first kernel's tile-locally sorted output in its VIRTUAL order (digit 0, source tile, position in
 //   the run).  Tile j of digit d = virtual positions [j T, (j + 1) T) of that digit's keys — full tiles, one partial tile per digit —
-//   found through ls_runscan_kernel's tables: S (first run the tile touches) and E (exclusive prefix of the run lengths); the tile's
-//   runs (~256 of ~64 keys, 4-byte aligned) go into a compacted list A[r] = source index - tile position, a bitmap marks where runs
-//   start, and every lane finds its run with one mbcnt on its item's 64 bits.  Plain (cached) loads: the XCD's L2 serves the lines
-//   two runs share (profiles/r04_probe_gather.txt: nt loads cost 0.07 ms per pass here).
+//   found through ls_runscan_kernel's tables: S (first run the tile touches) and E (exclusive prefix of the run lengths).  Every
+//   thread turns one (E, R) pair into a list entry {source index, tile position | length << 16}; wave w then loads runs w, w + 8, ...
+//   lane-contiguously straight into the stage (direct-to-LDS loads) and the keys are read back in tile order.
 // COUNT: the pass counts the next pass's table.   mode: bit0 descending (applies on the pass flagged PF_LAST)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KT, bool GATHER, bool COUNT>
@@ -591,8 +595,8 @@ __global__ __launch_bounds__(LS_THREADS, 4) void ls_pass_kernel(const uint32_t* 
                                                                  uint32_t* __restrict__ slices /*COUNT: [grid][LS_SLICE_WORDS]*/,
                                                                  uint32_t desc_off /*words: this pass's descriptor rows*/, uint32_t n,
                                                                  uint32_t pass /*1..3*/, uint32_t mode) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[LS_TILE];   // GATHER, while loading: the tile's run list
-    __shared__ __attribute__((aligned(16))) uint32_t s_whist[LS_WH_WORDS];  // GATHER, while loading: run-start bitmap (512 words)
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[LS_TILE];   // GATHER, while loading: the tile's keys in tile order
+    __shared__ __attribute__((aligned(16))) uint32_t s_whist[LS_WH_WORDS];  // GATHER, while loading: the tile's run list (512 entries of 8 bytes)
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[COUNT ? LS_TAB_WORDS : 4];
     __shared__ uint32_t s_gbase[RADIX];
     __shared__ uint32_t s_misc[64];
