@@ -182,6 +182,9 @@ static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && S
 #ifndef GS_HIST_PROBE
 #define GS_HIST_PROBE 1  // 0 (ablation): no skew probe, plain adds only
 #endif
+#ifndef GS_GHIST_WAVES_PER_SIMD
+#define GS_GHIST_WAVES_PER_SIMD (GS_GHIST_THREADS / 256)  // one workgroup per CU
+#endif
 #ifndef GS_HIST_UNROLL
 #define GS_HIST_UNROLL 4
 #endif
@@ -361,7 +364,7 @@ __host__ __device__ constexpr uint32_t hist_index(uint32_t q, uint32_t d, uint32
 // the sort reads its keys once for the histogram instead of once per word (8 x 4096 bins: 128 KiB of LDS).  A work item is
 // still HIST_CHUNK keys — two 16-byte loads per thread instead of one.
 template <int KT>
-__global__ __launch_bounds__(GHIST_THREADS) void global_histogram_kernel(const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(GHIST_THREADS, GS_GHIST_WAVES_PER_SIMD) void global_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                          uint32_t* slab, size_t slab_used_words,
                                                                          uint32_t n, uint32_t seg_len0, uint32_t p0,
                                                                          uint32_t np, uint32_t word,
