@@ -1620,6 +1620,18 @@ __device__ __forceinline__ void binning_body(
         const uint32_t dn = (kb >> (next_shift & 31u)) & 255u;
         if constexpr (PK) { if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 7) + (dn >> 1)], 1u << ((dn & 1u) * 16u)); }
         else { if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 8) + dn], 1u); }
+#ifdef GS_ABL_CNT  // ablation (timing only, results stay exact): bit 0: the address arithmetic once more; bit 1: the LDS add once more (adds 0)
+        if (GS_ABL_CNT & 1) {
+            uint32_t kb2 = kb, o2 = o;
+            asm volatile("" : "+v"(kb2), "+v"(o2));
+            const uint32_t dn2 = (kb2 >> (next_shift & 31u)) & 255u;
+            uint32_t idx2 = ((o2 >> seglog) << 7) + (dn2 >> 1), inc2 = 1u << ((dn2 & 1u) * 16u);
+            if (valid && dn2 != cnt_guess) asm volatile("" :: "v"(idx2), "v"(inc2));
+        }
+        if (GS_ABL_CNT & 2) {
+            if constexpr (PK) { if (valid && dn != cnt_guess) atomicAdd(&s_cnt[((o >> seglog) << 7) + (dn >> 1)], 0u); }
+        }
+#endif
     };
     const bool counting = POS == 1 && next_shift != 0xffffffffu;  // uniform
     if constexpr (POS == 1) {
