@@ -63,10 +63,19 @@ def onesweep_options_from_env(**overrides) -> "OneSweepOptions":
                 setattr(o, field, int(env[name], 0))
             except ValueError:
                 pass
+    _apply_overrides(o, overrides)
+    return o
+
+
+def _apply_overrides(o, overrides) -> None:
+    """Keyword overrides of an options struct: a name the struct does not have is a TypeError (setattr on a ctypes.Structure
+    would silently create a Python attribute and the option would be ignored)."""
+    known = {f[0] for f in o._fields_}
     for k, v in overrides.items():
+        if k not in known:
+            raise TypeError(f"{type(o).__name__} has no option {k!r} (known: {sorted(known)})")
         if v is not None:
             setattr(o, k, int(v))
-    return o
 
 
 def mgpu_options_from_env(**overrides) -> "MgpuOptions":
@@ -80,9 +89,7 @@ def mgpu_options_from_env(**overrides) -> "MgpuOptions":
                 setattr(o, field, int(os.environ[name], 0))
             except ValueError:
                 pass
-    for k, v in overrides.items():
-        if v is not None:
-            setattr(o, k, int(v))
+    _apply_overrides(o, overrides)
     return o
 
 
@@ -111,12 +118,14 @@ _PROTOS = [
     ("gs_onesweep_set_skip_passes", _int, [_vp, _int]),
     ("gs_onesweep_set_mid_path", _int, [_vp, _int]),
     ("gs_onesweep_set_plan", _int, [_vp, _int]),
+    ("gs_onesweep_last_plan", _int, [_vp, _u32p, _u32p, _vp]),
     ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_set_trace", _int, [_vp, _vp]),
     ("gs_debug_check_state", _int, [_vp, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_poke_status", _int, [_vp, _u32, _vp]),
     ("gs_debug_read_slab", _int, [_vp, _u32, _u32, _u32p, _vp]),
     ("gs_onesweep_global_histogram", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
+    ("gs_onesweep_scan", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_digit_pass", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _int, _int, _vp]),
     ("gs_onesweep_msd_prepare", _int, [_vp, _vp, _u32, _int, C.POINTER(_u32), _vp]),
     ("gs_onesweep_msd_partition", _int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),

@@ -14,7 +14,10 @@
 #include "../../include/gpusort.h"
 #include "onesweep_kernels.hpp"
 #include "mid_kernels.hpp"
+#include "hybrid_kernels.hpp"
+#ifdef GS_TUNING  // the round-4 local-sort plan: an experiment kept in the tuning build only (slower than the default)
 #include "ls_kernels.hpp"
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -164,6 +167,7 @@ constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb
 // workgroup per CU), up to 2^23 with 4-byte values (1024 x 16 wins from 2^24)
 inline uint32_t mid_keys(uint32_t vb) { return vb == 4 ? (1u << 23) : (1u << 25); }
 
+#ifdef GS_TUNING
 // ---- local-sort plan (ls_kernels.hpp): four launches, no histogram sweep ----
 using LsFirstLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, uint32_t* runs_t, uint32_t* slices, uint32_t* slab,
                                  size_t zero_end, uint32_t n, uint32_t plan);
@@ -195,6 +199,39 @@ const LsPassLauncher g_ls_pass[3][3] = {{launch_ls_pass<0, true, true>, launch_l
 inline uint32_t ls_nt_pad_for(uint32_t max_keys) { return ((div_up(max_keys, gs::LS_TILE) + 15u) & ~15u) + 272u; }
 // tables of the local-sort plan, words: R[256][nt_pad] | the first kernel's rows [nt_pad][256] | E[256][nt_pad] | S
 inline size_t ls_table_words(uint32_t max_keys) { const size_t p = ls_nt_pad_for(max_keys); return 3 * (size_t)gs::RADIX * p + gs::ls_stab_words((uint32_t)p); }
+#endif  // GS_TUNING
+
+// ---- two-level plan (hybrid_kernels.hpp) ----
+using HyHistLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n, uint32_t seg_len0,
+                                uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices);
+template <int KT>
+void launch_hy_hist(hipStream_t s, uint32_t grid, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n, uint32_t seg_len0,
+                    uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices) {
+    hipLaunchKernelGGL((gs::hy_histogram_kernel<KT>), dim3(grid), dim3(gs::HY_HIST_THREADS), 0, s, keys, slab, used_words, n, seg_len0, per_wg,
+                       wg_per_seg, slices);
+}
+using HyLocalLauncher = void (*)(hipStream_t, uint32_t* keys, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending);
+template <int KT, int T, int K>
+void launch_hy_local(hipStream_t s, uint32_t* keys, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending) {
+    hipLaunchKernelGGL((gs::hy_local_sort_kernel<KT, T, K>), dim3(gs::HY_BINS), dim3(T), 0, s, keys, tab, slab, n, descending);
+}
+// the local sort's workgroup by the mean bucket n / 65 536: it holds 1.5 x the mean at the top of its class (uniform keys stay within
+// a few per cent of the mean; what does not fit sends the sort to the LSD passes).  [class][key type]
+struct HyLocalClass { uint32_t max_n, cap; };
+constexpr HyLocalClass g_hy_class[4] = {{1u << 27, 256 * 12}, {1u << 28, 256 * 24}, {1u << 29, 512 * 24}, {GS_MAX_KEYS, 1024 * 24}};
+#ifdef GS_MINIMAL
+const HyHistLauncher g_hy_hist[3] = {launch_hy_hist<0>, nullptr, nullptr};
+const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, nullptr, nullptr}, {launch_hy_local<0, 256, 24>, nullptr, nullptr},
+                                          {launch_hy_local<0, 512, 24>, nullptr, nullptr}, {launch_hy_local<0, 1024, 24>, nullptr, nullptr}};
+#else
+const HyHistLauncher g_hy_hist[3] = {launch_hy_hist<0>, launch_hy_hist<1>, launch_hy_hist<2>};
+const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, launch_hy_local<1, 256, 12>, launch_hy_local<2, 256, 12>},
+                                          {launch_hy_local<0, 256, 24>, launch_hy_local<1, 256, 24>, launch_hy_local<2, 256, 24>},
+                                          {launch_hy_local<0, 512, 24>, launch_hy_local<1, 512, 24>, launch_hy_local<2, 512, 24>},
+                                          {launch_hy_local<0, 1024, 24>, launch_hy_local<1, 1024, 24>, launch_hy_local<2, 1024, 24>}};
+#endif
+inline int hy_class(uint32_t n) { return n <= g_hy_class[0].max_n ? 0 : n <= g_hy_class[1].max_n ? 1 : n <= g_hy_class[2].max_n ? 2 : 3; }
+constexpr uint32_t HY_MIN_KEYS_DEFAULT = (1u << 26) + 1u;  // below: buckets of a thousand keys — a workgroup per bucket is mostly launch
 
 }  // namespace
 
@@ -230,10 +267,17 @@ struct gs_onesweep {
     uint32_t hist_blocks_opt;  // gs_onesweep_options::hist_blocks (0 = the library picks)
     int first_pass_big;        // gs_onesweep_options::first_pass_big
     uint32_t debug_flags;      // gs_onesweep_options::debug_flags
-    int ls_plan;           // 1 = the local-sort plan for eligible sorts (gs_onesweep_set_plan), 0 = never (default)
+    int plan;              // gs_onesweep_options::plan / gs_onesweep_set_plan: 0 the library picks, 1 LSD passes only, 2 two-level plan wherever it can run
+    uint32_t hy_min_keys;  // plan 0: the two-level plan from this many keys up
+    uint32_t* hy_tab;      // the two-level plan's tables (gs::HYT_WORDS), nullptr: the handle cannot run it (pairs, 64-bit keys only ...)
+    uint32_t hy_grid;      // workgroups of its histogram kernel (a multiple of NCH)
+    int last_hy;           // the last sort was enqueued with the two-level plan's launches (whether it RAN on it is the device's decision: gs_onesweep_last_plan)
+#ifdef GS_TUNING
+    int ls_plan;           // 1 = the local-sort plan for eligible sorts (gs_onesweep_set_plan 3 / 4), 0 = never (default)
     uint32_t ls_min_keys;
     uint32_t* ls_runs;     // run table of the first kernel: [256][ls_nt_pad] words
     uint32_t ls_nt_pad;
+#endif
     bool exp_keep_desc;  // experiment builds (GS_EXP & 1024): the histogram kernel leaves the descriptor rows alone
 };
 
@@ -241,6 +285,8 @@ namespace {
 
 size_t slab_words_for(uint32_t max_keys) {
     // descriptor rows: four passes on the smallest tile, or the eight passes of a 64-bit sort on its 8192-key tile
+    // (two-level plan: its second pass has CHMAX chains — on 16 384-key tiles, from 2^20 keys up at the earliest: covered by the rows of
+    //  the smallest tile as soon as max_keys / 4096 - max_keys / 16 384 >= 2 * CHMAX, i.e. from 2^12 x 171 keys)
     const size_t rows4 = 4 * ((size_t)div_up(max_keys, MIN_TILE) + 2 * gs::MAXCH + 2);
     const size_t rows8 = gs::MAX_PASSES * ((size_t)div_up(max_keys, KEY64_TILE) + 2 * gs::MAXCH + 2);
     return SLAB_DESC + (rows4 > rows8 ? rows4 : rows8) * (size_t)gs::RADIX;
@@ -292,6 +338,12 @@ uint32_t pos_grid() {
     return 2u * cus;
 }
 
+// workgroups of the two-level plan's histogram kernel: one per CU, a multiple of NCH (position segments get equal numbers of them)
+uint32_t hy_grid_for_device() {
+    const uint32_t cus = pos_grid() / 2u;
+    return cus >= gs::NCH ? cus / gs::NCH * gs::NCH : gs::NCH;
+}
+
 // most workgroups the histogram kernel is ever launched with for a handle of max_keys keys (sizes its slices)
 uint32_t hist_blocks_cap(uint32_t max_keys, uint32_t forced = 0) {
     uint32_t m = hist_blocks(max_keys);
@@ -309,16 +361,20 @@ struct PassPlan {
     uint32_t grid0;  // grid of the plan's first pass (shape0_index)
 };
 // shape0_index >= 0: the plan's first pass runs on that (larger) tile shape, the others on shape_index
+// hy: the sort may run on the two-level plan (hybrid_kernels.hpp): its histogram sweep replaces GlobalHistogram, its scan runs in front
+// of the ordinary one, and both plans' launches follow (sort_impl)
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
                    uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0, int shape0_index = -1,
-                   uint32_t pos_tile = POS_TILE) {
+                   uint32_t pos_tile = POS_TILE, bool hy = false) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
+    h->last_hy = hy ? 1 : 0;
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
     const uint32_t tile = (uint32_t)sh.threads * sh.kpt;
     const uint32_t tile0 = shape0_index < 0 ? tile : (uint32_t)g_shapes[shape0_index].threads * g_shapes[shape0_index].kpt;
     const uint32_t tiles = div_up(n, tile < tile0 ? tile : tile0);
     // every chain: its tiles (+1 partial) + row 0; bit 2 of the plan: the sort may end up on the (smaller) position-chain tiles
-    const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + 2 * gs::MAXCH + 2;
+    // (two-level plan: its second pass runs on CHMAX chains)
+    const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + (hy ? 2 * gs::CHMAX + 8 : 2 * gs::MAXCH + 2);
     const uint32_t desc_stride = rows * gs::RADIX;
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
@@ -338,12 +394,24 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     if (rec) GS_HIP(hipEventRecord(h->ev[0], s));
     if (rec) GS_HIP(hipEventRecord(h->ev[1], s));
     h->hist_dirty = true;  // until the caller has launched whatever zeroes HIST again
+    if (hy) {
+        // one workgroup per CU at most, NCH position segments of equal numbers of workgroups, every workgroup >= one tile of keys
+        const uint32_t seg_tiles = seg_len0 / tile0;
+        const uint32_t wg_per_seg = seg_tiles < h->hy_grid / gs::NCH ? (seg_tiles ? seg_tiles : 1u) : h->hy_grid / gs::NCH;
+        const uint32_t G = wg_per_seg * gs::NCH;
+        const uint32_t per_wg = div_up(div_up(seg_len0, wg_per_seg), gs::HIST_CHUNK) * gs::HIST_CHUNK;
+        g_hy_hist[kt](s, G, static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, per_wg, wg_per_seg, h->partials);
+        hipLaunchKernelGGL(gs::hy_reduce_kernel, dim3(gs::RADIX + gs::NCH), dim3(256), 0, s, h->partials, G, wg_per_seg, h->hy_tab, h->slab + SLAB_HIST);
+        if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
+        hipLaunchKernelGGL(gs::hy_scan_kernel, dim3(1), dim3(1024), 0, s, h->slab, h->hy_tab, n, seg_len0, desc_stride, g_hy_class[hy_class(n)].cap, tile);
+    } else {
     g_hist[kt](s, hist_blocks(n, h->hist_blocks_opt), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
                (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u, h->partials);
+    }
 #if (GS_EXP & 2)
     GS_HIP(hipMemcpyAsync(h->slab + SLAB_STATUS + 8, &h->trace_buf, sizeof(void*), hipMemcpyHostToDevice, s));
 #endif
-    if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
+    if (rec && !hy) GS_HIP(hipEventRecord(h->ev[2], s));
     if (np > 4)  // 64-bit keys: all eight passes from one sweep
         hipLaunchKernelGGL(gs::scan_kernel<8>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
                            h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, pos_tile, tile0);
@@ -351,7 +419,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
         hipLaunchKernelGGL(gs::scan_kernel<4>, dim3(np), dim3(256), 0, s, h->slab + SLAB_HIST, h->slab + SLAB_DESC,
                            h->slab + SLAB_INFO, desc_stride, n, seg_len0, tile, scan_plan, pos_tile, tile0);
     if (rec) GS_HIP(hipEventRecord(h->ev[3], s));
-    plan->grid = div_up(n, tile) + gs::MAXCH + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
+    plan->grid = div_up(n, tile) + (hy ? gs::CHMAX : gs::MAXCH) + 1;  // chains end in partial tiles: at most one more tile per chain than n/tile
     plan->grid0 = div_up(n, tile0) + gs::MAXCH + 1;
     plan->desc_stride = desc_stride;
     h->last_n = n; h->last_tile = tile; h->last_tile0 = tile0; h->last_p0 = p0; h->last_np = np; h->last_dyn = (scan_plan & 2u) ? 1u : 0u; h->last_pos_tile = pos_tile;
@@ -457,6 +525,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u, h->slab + SLAB_STATUS);
         h->last_tile = 0;
+        h->last_hy = 0;
         if (h->profiling)  // everything is charged to slot 0 (and the total)
             for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
         GS_HIP(hipGetLastError());
@@ -473,6 +542,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                               d_vals, d_alt_vals, h->slab + gs::SLAB_MID, h->slab + SLAB_STATUS, n,
                                               order == GS_ORDER_DESCENDING ? 1u : 0u);
         h->last_tile = 0;
+        h->last_hy = 0;
         if (h->profiling)  // everything is charged to slot 0 (and the total)
             for (int e = 1; e <= 7; ++e) GS_HIP(hipEventRecord(h->ev[e], s));
         GS_HIP(hipGetLastError());
@@ -480,7 +550,8 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         return GS_OK;
     }
 #endif
-    // Local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys on the default routing, LDS-atomic ranking.  Four launches:
+#ifdef GS_TUNING
+    // Local-sort plan (ls_kernels.hpp; tuning build only): keys-only sorts of 32-bit keys on the default routing, LDS-atomic ranking.  Four launches:
     // the first kernel sorts every tile locally by digit 0 (keys -> alt) and counts what the gather pass needs; gather pass
     // (alt -> keys), two plain passes (keys -> alt -> keys).  No histogram sweep, no Scan launch: 32 bytes per key.
     if (h->ls_plan && h->ls_runs && vb == 0 && !is_key64(kt) && h->rank_mode == 1 && h->shape_auto && h->skip_passes &&
@@ -524,6 +595,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         h->profile_pending = h->profiling != 0;
         return GS_OK;
     }
+#endif  // GS_TUNING
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
     // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
     const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 &&
@@ -550,6 +622,12 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const bool pos = dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
                      (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
                      (vb == 4 ? sh.threads * sh.kpt == 16384 : (sh.threads == 512 && sh.kpt == 32));  // (the plan's last pass runs on 16 384-key tiles)
+    // Two-level plan (hybrid_kernels.hpp): keys-only sorts of 32-bit keys that may also run on position chains (its fall-back when
+    // the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
+    // (position_chains = 2 asks for the position-chain plan whatever the keys look like: only plan 2 overrides that)
+    const bool hy = pos && vb == 0 && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
+                    (h->plan == 2 || (n >= h->hy_min_keys && h->pos_chains != 2)) &&
+                    (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, POS_TILE) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
@@ -570,7 +648,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0, pos_tile_for(vb));
+        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0, pos_tile_for(vb), hy);
         if (st != GS_OK) return st;
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
         for (uint32_t p = 0; p < NP; ++p) {
@@ -578,11 +656,19 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
             const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == NP - 1) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
             // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
             const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
-            if (pos && vb == 0)  // one launch serves both plans (persistent workgroups, two per CU)
+            if (pos && vb == 0) {  // one launch serves both plans (persistent workgroups, two per CU)
+                // two-level plan: the first two launches are pass A / pass B or LSD passes 0 / 1 — digit and chain count come from the
+                // info block (mode bits 7, 8); the bucket-local sort follows them; LSD passes 2 and 3 exit on PF_SKIP if it ran
                 g_dual[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-                                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8, mode);
-            else
+                                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
+                                   mode | ((hy && p < 2) ? 128u | 256u : 0u));
+                if (hy && p == 1) {
+                    if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
+                    if (!(h->debug_flags & 0x40000000u))  // (bring-up aid, tools/hy_bringup.py: leave pass B's output as it is)
+                        g_hy_local[hy_class(n)][kt](s, k[0], h->hy_tab, h->slab, n, desc_bit);
+                }
+            } else
                 (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
@@ -597,7 +683,7 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
                                    (mode & ~4u) | 64u);
-            if (h->profiling && word == 0 && p < 4) GS_HIP(hipEventRecord(h->ev[4 + p], s));
+            if (h->profiling && word == 0 && p < 4 && !(hy && p == 1)) GS_HIP(hipEventRecord(h->ev[4 + p], s));
         }
     }
     if (h->profiling && is_key64(kt)) GS_HIP(hipEventRecord(h->ev[7], s));  // slot 6 then holds pass 3 and everything behind it
@@ -651,8 +737,10 @@ const char* gs_status_string(gs_status s) {
 int gs_last_hip_error(void) { return g_last_hip_error; }
 
 size_t gs_onesweep_temp_bytes(uint32_t max_keys) {
-    return (slab_words_for(max_keys) + (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS +
-            (max_keys > (1u << 25) ? ls_table_words(max_keys) : 0)) * sizeof(uint32_t);
+    // an upper bound over modes and options (default hist_blocks): slab + the histogram workgroups' slices + the two-level plan's tables
+    const size_t slices = (size_t)hist_blocks_cap(max_keys) * gs::HIST_TABLE_WORDS, hy_slices = (size_t)hy_grid_for_device() * gs::HY_SLICE_WORDS;
+    const bool hy = max_keys > (1u << 20);
+    return (slab_words_for(max_keys) + (hy && hy_slices > slices ? hy_slices : slices) + (hy ? gs::HYT_WORDS : 0)) * sizeof(uint32_t);
 }
 
 uint32_t gs_onesweep_partition_size(gs_mode mode, uint32_t value_bytes) {
@@ -688,7 +776,12 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
         if (options->struct_size != sizeof(gs_onesweep_options)) return GS_ERR_ARG;  // (one layout so far)
         o = *options;
     }
-    if (o.rank_mode < -1 || o.rank_mode > 1 || o.position_chains < 0 || o.position_chains > 2 || o.plan < 0 || o.plan > 2 ||
+#ifdef GS_TUNING
+    const int max_plan = 4;  // 3 / 4: the round-4 local-sort plan (at its own size / at every size)
+#else
+    const int max_plan = 2;
+#endif
+    if (o.rank_mode < -1 || o.rank_mode > 1 || o.position_chains < 0 || o.position_chains > 2 || o.plan < 0 || o.plan > max_plan ||
         (o.key64_sweeps != 1 && o.key64_sweeps != 2) || o.position_chains_min_log2 < 20 || o.position_chains_min_log2 > 30)
         return GS_ERR_ARG;
     int shape_pick = -1;
@@ -733,10 +826,17 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->msd_keys = nullptr;
     h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = h->last_pos_tile = 0;
     h->hist_dirty = false;
-    h->ls_plan = 0;  // opt-in until it beats the GlobalHistogram / Scan / 4-pass pipeline on uniform keys (set below once the tables exist)
+    h->plan = o.plan <= 2 ? o.plan : 0;
+    h->hy_min_keys = HY_MIN_KEYS_DEFAULT;
+    h->hy_tab = nullptr;
+    h->hy_grid = hy_grid_for_device();
+    h->last_hy = 0;
+#ifdef GS_TUNING
+    h->ls_plan = 0;  // opt-in: slower than the default
     h->ls_min_keys = (1u << 25) + 1u;  // (below: the 8192-key tile and the two-launch routes)
     h->ls_runs = nullptr;
     h->ls_nt_pad = ls_nt_pad_for(max_keys);
+#endif
     h->exp_keep_desc = false;
     h->msd_n = h->msd_grid = 0;
     h->msd_kt = GS_KEY_UINT32;
@@ -747,9 +847,18 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->rank_mode = o.rank_mode >= 0 ? o.rank_mode : (lds_atomic_order_ok() ? 1 : 0);
     h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&h->partials, (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS * sizeof(uint32_t));
-    if (e == hipSuccess && mode == GS_MODE_KEYS_ONLY && max_keys >= h->ls_min_keys)  // the run table of the local-sort plan (16 MiB at 2^28 keys)
-        e = hipMalloc(&h->ls_runs, ls_table_words(max_keys) * sizeof(uint32_t));  // run table, its prefix, tile -> run table (16 + 16 + 16 MiB at 2^28 keys)
+    // the two-level plan: keys-only handles that can hold a sort of its size class (the position-chain plan, its fall-back, starts at 2^20 keys)
+    const bool hy_handle = mode == GS_MODE_KEYS_ONLY && max_keys > (1u << 20) && o.plan != 1;
+    {
+        size_t slice_words = (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS;
+        if (hy_handle && (size_t)h->hy_grid * gs::HY_SLICE_WORDS > slice_words) slice_words = (size_t)h->hy_grid * gs::HY_SLICE_WORDS;
+        if (e == hipSuccess) e = hipMalloc(&h->partials, slice_words * sizeof(uint32_t));
+    }
+    if (e == hipSuccess && hy_handle) e = hipMalloc(&h->hy_tab, gs::HYT_WORDS * sizeof(uint32_t));
+#ifdef GS_TUNING
+    if (e == hipSuccess && mode == GS_MODE_KEYS_ONLY && max_keys >= h->ls_min_keys && o.plan >= 3)  // the run tables of the local-sort plan (48 MiB at 2^28 keys)
+        e = hipMalloc(&h->ls_runs, ls_table_words(max_keys) * sizeof(uint32_t));
+#endif
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
     if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_DESC * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
@@ -757,11 +866,16 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
         g_last_hip_error = (int)e;
         if (h->slab) (void)hipFree(h->slab);
         if (h->partials) (void)hipFree(h->partials);
+        if (h->hy_tab) (void)hipFree(h->hy_tab);
+#ifdef GS_TUNING
         if (h->ls_runs) (void)hipFree(h->ls_runs);
+#endif
         delete h;
         return GS_ERR_HIP;
     }
-    if (o.plan != 0 && h->ls_runs) h->ls_plan = o.plan;  // (a handle without the plan's tables stays on the default pipeline)
+#ifdef GS_TUNING
+    if (o.plan >= 3 && h->ls_runs) h->ls_plan = o.plan - 2;  // (a handle without the plan's tables stays on the default pipeline)
+#endif
     *out = h;
     return GS_OK;
 }
@@ -773,7 +887,10 @@ gs_status gs_onesweep_destroy(gs_onesweep* h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->slab) (void)hipFree(h->slab);
     if (h->partials) (void)hipFree(h->partials);
+    if (h->hy_tab) (void)hipFree(h->hy_tab);
+#ifdef GS_TUNING
     if (h->ls_runs) (void)hipFree(h->ls_runs);
+#endif
     delete h;
     return GS_OK;
 }
@@ -790,10 +907,32 @@ gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count
     return GS_OK;
 }
 
-gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort) {
-    if (!h || local_sort < 0 || local_sort > 2) return GS_ERR_ARG;
-    if (local_sort != 0 && !h->ls_runs) return GS_ERR_MODE;  // (the handle was created without the plan's tables: pairs, or max_keys <= 2^25)
-    h->ls_plan = local_sort;
+gs_status gs_onesweep_set_plan(gs_onesweep* h, int plan) {
+    if (!h || plan < 0) return GS_ERR_ARG;
+#ifdef GS_TUNING
+    if (plan == 3 || plan == 4) {  // the round-4 local-sort plan
+        if (!h->ls_runs) return GS_ERR_MODE;
+        h->ls_plan = plan - 2;
+        return GS_OK;
+    }
+    h->ls_plan = 0;
+#endif
+    if (plan > 2) return GS_ERR_ARG;
+    if (plan == 2 && !h->hy_tab) return GS_ERR_MODE;  // (the handle was created without the plan's tables: pairs, max_keys <= 2^20, or plan 1 at create)
+    h->plan = plan;
+    return GS_OK;
+}
+
+gs_status gs_onesweep_last_plan(gs_onesweep* h, uint32_t* plan, uint32_t* largest_bucket, void* stream) {
+    if (!h || !plan) return GS_ERR_ARG;
+    *plan = 0;
+    if (largest_bucket) *largest_bucket = 0;
+    if (!h->last_hy) return GS_OK;  // the last sort was not offered the two-level plan (size, mode, options): LSD passes, or a one- / two-launch route
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GS_HIP(hipMemcpyAsync(h->pinned, h->slab + gs::SLAB_HY, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GS_HIP(hipStreamSynchronize(s));
+    *plan = h->pinned[gs::HY_VALID] ? 1u : 0u;
+    if (largest_bucket) *largest_bucket = h->pinned[gs::HY_MAXBUCKET];
     return GS_OK;
 }
 
@@ -952,7 +1091,7 @@ gs_status gs_debug_check_state(gs_onesweep* h, uint64_t report[8], void* stream)
     gs_status ret = GS_OK;
     if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) != hipSuccess) ret = GS_ERR_HIP;
     if (ret == GS_OK) {
-        hipLaunchKernelGGL(gs::check_state_kernel, dim3(gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
+        hipLaunchKernelGGL(gs::check_state_kernel, dim3(h->last_hy ? gs::CHMAX : gs::MAXCH, h->last_np), dim3(256), 0, s, h->slab, h->last_desc_stride,
                            h->last_tile, 0u, h->last_dyn, d, h->last_pos_tile, h->last_tile0);
         if (hipMemcpyAsync(report, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
@@ -981,6 +1120,24 @@ gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint3
             for (uint32_t x = 0; x < gs::NCH; ++x) g += h->pinned[gs::hist_index(q, d, x)];
             h_hist[q * gs::RADIX + d] = g;
         }
+    return GS_OK;
+}
+
+gs_status gs_onesweep_scan(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, uint32_t* h_rows, void* stream) {
+    if (!h || !d_keys || !h_rows || misaligned(d_keys) || (int)kt < 0 || (int)kt > 2) return GS_ERR_ARG;
+    if (n == 0 || n > h->max_keys) return GS_ERR_SIZE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PassPlan plan;
+    gs_status st = prologue(h, d_keys, n, kt, s, 0, 4, &plan);
+    if (st != GS_OK) return st;
+    // chain 0 of every pass starts at row 0 of the pass's descriptor region: its seed row holds the digit starts themselves
+    for (uint32_t q = 0; q < 4; ++q)
+        GS_HIP(hipMemcpyAsync(h->pinned + q * gs::RADIX, h->slab + SLAB_DESC + (size_t)q * plan.desc_stride, gs::RADIX * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, s));
+    GS_HIP(zero_hist(h, s));  // no pass follows: hand HIST back zeroed
+    h->hist_dirty = false;
+    GS_HIP(hipStreamSynchronize(s));
+    memcpy(h_rows, h->pinned, 4 * gs::RADIX * sizeof(uint32_t));
     return GS_OK;
 }
 

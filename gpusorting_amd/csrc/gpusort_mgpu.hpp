@@ -171,6 +171,8 @@ struct gs_mgpu {
     int overlap;               // values on the second stream (gs_mgpu_options::overlap, default 1)
     int alltoallv;             // the RCCL transport exchanges through ncclAllToAllv (gs_mgpu_options::alltoallv)
     int failed;                // a call on this context has failed: destroy aborts the communicators
+    bool call_complete = true; // the last gs_onesweep_sort_sharded ran through its closing status gather and returned GS_OK on this
+                               // rank: only then are d_status[1..world] THIS call's words (gs_mgpu_check reads nothing otherwise)
     int debug_fail;            // test hook: 1 = fail before the gather, 2 = fail after the plan (next call only)
     uint32_t *part_keys;       // shard grouped by destination; alt buffer of the local sort afterwards
     void* part_vals;
@@ -413,6 +415,7 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
     gs_onesweep* h = c->sorter;
     *out_n = 0;
     c->prof_pending = false;
+    c->call_complete = false;  // until this call's closing gather is behind us: the status words on the device are an EARLIER call's
     c->last_sent = c->last_recv = 0;
     c->last_fine = 0;
     GS_HIP(hipEventRecord(c->ev[0], s));
@@ -532,12 +535,20 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
     GS_HIP(hipEventRecord(c->ev[3], s));
     *out_n = n_recv;
     c->prof_pending = true;
+    c->call_complete = true;
     return GS_OK;
 }
 
 gs_status gs_mgpu_check(gs_mgpu* c, void* stream) {
     if (!c) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!c->call_complete) {
+        // The last call returned an error on this rank before or at its closing gather (plan error, a failed peer, the gather
+        // itself) or behind it (the local sort): d_status[1..world] still hold an EARLIER call's words — reading them would
+        // report GS_OK and clear the failure latch while collectives may still be in flight.  The latch stays.
+        GS_HIP(hipStreamSynchronize(s));
+        return GS_ERR_COMM;
+    }
     GS_HIP(hipMemcpyAsync(c->h_status, c->d_status, (c->world + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GS_HIP(hipStreamSynchronize(s));
     if (c->world > 1 || c->force_exchange)

@@ -1,0 +1,491 @@
+// hybrid_kernels.hpp — the TWO-LEVEL plan of large sorts of 32-bit keys (round 5): 28 bytes of HBM traffic per key instead of 36.
+//
+// The reference's OneSweep (GPUSortingCUDA/Sort/OneSweep.cu:44-600; dispatch OneSweepDispatcher.cuh:311-363) is one histogram
+// sweep + four 8-bit LSD passes: 4 + 4 x 8 = 36 B/key.  On MI355X each pass already runs at the floor of its access shape
+// (DESIGN.md 3.3), so the only lever left is bytes per key.  This plan keeps the reference's kernels — ONE GlobalHistogram sweep,
+// a Scan, DigitBinningPasses with chained-scan decoupled look-back — but orders the work so that the last two digits never leave
+// the chip:
+//   hy_histogram_kernel   one sweep over the keys (the GlobalHistogram of OneSweep.cu:44-123): the 65 536-bin histogram of the keys'
+//                         TOP 16 bits, packed 2 x 16 bit in 128 KiB of LDS per workgroup — ONE LDS add per key on it (the LSD
+//                         plan's joint tables cost three) — plus the digit-0 counts per position segment that the LSD plans need,
+//                         should this plan not apply.  The kernel is also the sort's clear, as global_histogram_kernel is.
+//   hy_reduce_kernel      sum of the workgroups' slices -> joint32[65 536], per-segment top-byte counts, per-segment digit-0 counts
+//   hy_scan_kernel        (the Scan of OneSweep.cu:125-162) exclusive scan of the 65 536 bins = start of every 16-bit-prefix bucket;
+//                         DECIDES on the device whether the plan is valid — no counter overflow, no bucket above what one
+//                         workgroup sorts in LDS — and then writes the info blocks, chain tables and seed rows of
+//   pass A                DigitBinningPass on the TOP byte   (keys -> alt; 16 position chains, as the first pass of any sort), and
+//   pass B                DigitBinningPass on byte 2         (alt -> keys; 256 chains = the top-byte buckets pass A just made: every
+//                         tile lies inside one bucket, its 256 digit runs are seeded with that bucket's 16-bit-prefix starts)
+//                         — both are the SAME kernels as the LSD passes (binning_body), told their digit and chain count by the
+//                         info block — and
+//   hy_local_sort_kernel  one workgroup per 16-bit-prefix bucket (n / 65 536 keys on average): loads the bucket, sorts it on the low
+//                         16 bits by two stable 8-bit passes in LDS, and writes it back IN PLACE — sequential reads and writes.
+// (stable by byte 3) o (stable by byte 2 inside each byte-3 bucket) o (stable by the low 16 bits inside each 16-bit bucket) is
+// the stable sort by the whole key: the result is bit-identical to the four LSD passes, values included.
+//
+// If the plan is not valid — skewed keys: presets 2-5 of the reference's entropy sweep put 10 %-60 % of the keys under one
+// prefix — hy_scan_kernel raises HX_SKEW instead and the ordinary scan_kernel plans the four LSD passes on position chains
+// (PF_POS) from the digit-0 counts of the same sweep: no key is read twice for the decision, nothing returns to the host.
+// Every launch of a sort is enqueued regardless; the ones the other plan owns exit on their flag word (PF_SKIP / the valid word).
+#pragma once
+#include "onesweep_kernels.hpp"
+#include "mid_kernels.hpp"
+
+namespace gs {
+
+constexpr uint32_t HY_BINS = 65536;               // values of a key's top 16 bits
+constexpr uint32_t HY_JOINT_WORDS = HY_BINS / 2;  // the workgroup's table: two 16-bit counters per word
+constexpr uint32_t HY_SLICE_WORDS = HY_JOINT_WORDS + RADIX;  // what a histogram workgroup hands on: its joint table + its digit-0 counts
+// words of the slab's HY region
+constexpr uint32_t HY_VALID = 0;      // 1: the sort runs on this plan (hy_local_sort_kernel's licence; zero whenever a sort starts)
+constexpr uint32_t HY_MAXBUCKET = 1;  // largest 16-bit-prefix bucket (diagnostics)
+// the plan's tables (an allocation of their own: nothing in them has to be zero when a sort starts)
+constexpr uint32_t HYT_JOINT = 0;                       // joint32[65 536]: keys per 16-bit prefix
+constexpr uint32_t HYT_BASE = HY_BINS;                  // base[65 536 + 1]: start of every prefix's bucket in the sorted order
+constexpr uint32_t HYT_T = HYT_BASE + HY_BINS + 64;     // T[NCH][256]: keys of position segment x whose top byte is d
+constexpr uint32_t HYT_WORDS = HYT_T + NCH * RADIX;
+static_assert(HYT_BASE % 4 == 0 && HYT_T % 4 == 0, "16-byte accesses");
+
+constexpr int HY_HIST_THREADS = 1024;
+constexpr uint32_t HY_FOLD_CHUNKS = 256;  // the digit-0 replicas are folded at least this often (see global_histogram_kernel)
+
+// ---------------------------------------------------------------------------
+// Histogram sweep.  Workgroup w counts ONE contiguous range of keys inside one position segment of the first pass:
+// segment x = w / wg_per_seg, range j = w % wg_per_seg of per_wg keys (a multiple of HIST_CHUNK).
+//   s_j   the 16-bit-prefix table, 2 x 16 bit per word.  Random prefixes: one add per key, bank = 6 address bits of the prefix.
+//         A counter that wraps loses 65 536 (high half) or 65 535 (low half carries into its neighbour) from the table's SUM, never
+//         adds to it — so "sum of the decoded table == keys counted" is an EXACT test for "no counter wrapped", made when the
+//         table is written out.  Dominant prefixes (sorted input, constant top bytes, skew) are counted with one add of a ballot's
+//         popcount per wave, as in global_histogram_kernel.
+//   s_r   digit 0 on 32 lane-private 16-bit replicas (never a bank conflict), folded into s_b0.
+// ---------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_histogram_kernel(
+    const uint32_t* __restrict__ keys, uint32_t* slab, size_t slab_used_words, uint32_t n, uint32_t seg_len0, uint32_t per_wg,
+    uint32_t wg_per_seg, uint32_t* slices) {
+    static_assert(KeyWords<KT>::value == 1, "32-bit keys");
+    constexpr uint32_t T = HY_HIST_THREADS;
+    __shared__ __attribute__((aligned(16))) uint32_t s_j[HY_JOINT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_r[RADIX / 2 * 32];
+    __shared__ uint32_t s_b0[RADIX];
+    __shared__ uint32_t s_red[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t* hist = slab + SLAB_HIST;
+    // the sort's clear (see global_histogram_kernel): everything nobody reads before this kernel ends
+    {
+        uint4* a = reinterpret_cast<uint4*>(slab);
+        const size_t na = SLAB_HIST / 4, b0 = SLAB_HSUB / 4, nb = slab_used_words / 4;
+        const size_t stride = (size_t)gridDim.x * T;
+        const uint4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = (size_t)blockIdx.x * T + tid; i < na; i += stride) a[i] = z;
+        for (size_t i = b0 + (size_t)blockIdx.x * T + tid; i < nb; i += stride) a[i] = z;
+    }
+    for (uint32_t i = tid; i < HY_JOINT_WORDS / 4; i += T) reinterpret_cast<uint4*>(s_j)[i] = uint4{0u, 0u, 0u, 0u};
+    for (uint32_t i = tid; i < RADIX / 2 * 32 / 4; i += T) reinterpret_cast<uint4*>(s_r)[i] = uint4{0u, 0u, 0u, 0u};
+    if (tid < RADIX) s_b0[tid] = 0;
+    if (tid < 4) s_red[tid] = 0;
+    // eight threads share the 32 replicas of a counter pair (see global_histogram_kernel's fold)
+    auto fold = [&]() {
+        __syncthreads();
+        for (uint32_t i = tid; i < RADIX / 2 * 8; i += T) {
+            const uint4 v = reinterpret_cast<const uint4*>(s_r)[i];
+            reinterpret_cast<uint4*>(s_r)[i] = uint4{0u, 0u, 0u, 0u};
+            uint32_t lo = (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+            uint32_t hi = (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                lo += __shfl_xor(lo, m, 64);
+                hi += __shfl_xor(hi, m, 64);
+            }
+            if ((i & 7u) == 0u) {
+                s_b0[(i >> 3) * 2u] += lo;
+                s_b0[(i >> 3) * 2u + 1u] += hi;
+            }
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+
+    const uint32_t x = blockIdx.x / wg_per_seg, jr = blockIdx.x % wg_per_seg;
+    const unsigned long long sb = (unsigned long long)x * seg_len0, se = sb + seg_len0;
+    const uint32_t seg_begin = sb < n ? (uint32_t)sb : n, seg_end = se < n ? (uint32_t)se : n;
+    const unsigned long long rb = (unsigned long long)seg_begin + (unsigned long long)jr * per_wg;
+    const uint32_t begin = rb < seg_end ? (uint32_t)rb : seg_end;
+    const uint32_t end = (unsigned long long)begin + per_wg < seg_end ? begin + per_wg : seg_end;
+
+    uint32_t k_or = 0, k_nand = 0;
+    bool skew = false;               // wave-uniform: a dominant prefix was seen; cleared when it fades
+    uint32_t sticky = 0xffffffffu;   // wave-uniform guess of it
+    uint32_t since_fold = 0;
+    typedef uint32_t hv4 __attribute__((ext_vector_type(4)));
+    auto ld16 = [](const uint32_t* q) -> uint4 {
+        const hv4 v = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(q));
+        return uint4{v.x, v.y, v.z, v.w};
+    };
+    auto add_joint = [&](uint32_t p, uint32_t c) { atomicAdd(&s_j[p >> 1], c << ((p & 1u) << 4)); };
+    // four keys of this thread (radix-sortable form); probe: look for a dominant prefix first (once per work item)
+    auto process = [&](const uint4 t, const bool probe) {
+        const uint32_t b[4] = {t.x, t.y, t.z, t.w};
+        k_or |= t.x | t.y | t.z | t.w;
+        k_nand |= ~(t.x & t.y & t.z & t.w);
+        if (since_fold >= HY_FOLD_CHUNKS) {  // uniform
+            fold();
+            since_fold = 0;
+        }
+        ++since_fold;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t d = b[j] & 255u;
+            atomicAdd(&s_r[(d >> 1) * 32u + (lane & 31u)], 1u << ((d & 1u) * 16u));
+        }
+        if (probe) {
+            const uint32_t p0 = b[0] >> 16;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+            const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(p0 == f));
+            if (pc >= GS_HIST_SKEW_LANES) {
+                skew = true;
+                if (pc >= 24 || sticky == 0xffffffffu) sticky = f;
+            }
+        }
+        if (!skew) {  // uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) add_joint(b[j] >> 16, 1u);
+            return;
+        }
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b[0] >> 16));
+        const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((b[0] >> 16) == f));
+        uint32_t hit = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = b[j] >> 16;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(p == sticky);
+            hit += (uint32_t)__popcll(m);
+            if (p != sticky) add_joint(p, 1u);
+            else if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u)
+                add_joint(sticky, (uint32_t)__popcll(m));
+        }
+        if (hit < 32) {  // the guess covers < 1/8 of the lanes: relearn, or leave skew mode
+            sticky = f;
+            if (pc < 8) skew = false;
+        }
+    };
+    // One work item = 4 consecutive chunks; all their 16-byte loads are issued before the first is consumed.
+    constexpr uint32_t UNROLL = 4;
+    for (uint32_t c0 = begin; c0 < end; c0 += UNROLL * HIST_CHUNK) {
+        if ((unsigned long long)c0 + UNROLL * HIST_CHUNK <= end) {
+            uint4 t[UNROLL];
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; ++u) t[u] = ld16(keys + c0 + u * HIST_CHUNK + tid * 4u);
+#pragma unroll
+            for (uint32_t u = 0; u < UNROLL; ++u)
+                process(uint4{to_bits<KT>(t[u].x), to_bits<KT>(t[u].y), to_bits<KT>(t[u].z), to_bits<KT>(t[u].w)}, u == 0);
+            continue;
+        }
+        for (uint32_t c = c0; c < end; c += HIST_CHUNK) {  // the range's last, partial work item
+            if ((unsigned long long)c + HIST_CHUNK <= end) {
+                const uint4 t = ld16(keys + c + tid * 4u);
+                process(uint4{to_bits<KT>(t.x), to_bits<KT>(t.y), to_bits<KT>(t.z), to_bits<KT>(t.w)}, true);
+            } else {
+                for (uint32_t i = c + tid; i < end; i += T) {
+                    const uint32_t kb = to_bits<KT>(keys[i]);
+                    k_or |= kb;
+                    k_nand |= ~kb;
+                    add_joint(kb >> 16, 1u);
+                    atomicAdd(&s_b0[kb & 255u], 1u);
+                }
+            }
+        }
+    }
+    fold();
+    // the workgroup's slice: the packed table as it is (coalesced 16-byte stores) + the digit-0 counts; the overflow test on the way
+    uint32_t* mine = slices + (size_t)blockIdx.x * HY_SLICE_WORDS;
+    uint32_t sum = 0;
+    for (uint32_t i = tid; i < HY_JOINT_WORDS / 4; i += T) {
+        const uint4 v = reinterpret_cast<const uint4*>(s_j)[i];
+        reinterpret_cast<uint4*>(mine)[i] = v;
+        sum += (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16) + (v.z & 0xffffu) + (v.z >> 16) + (v.w & 0xffffu) + (v.w >> 16);
+    }
+    if (tid < RADIX) mine[HY_JOINT_WORDS + tid] = s_b0[tid];
+    sum = wave_reduce_sum(sum);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+        k_or |= __shfl_xor(k_or, dd, 64);
+        k_nand |= __shfl_xor(k_nand, dd, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&s_red[0], sum);
+        atomicOr(&s_red[1], k_or);
+        atomicOr(&s_red[2], k_nand);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_red[0] != end - begin) atomicOr(&hist[HIST_TABLE_WORDS + HX_HY_BAD], 1u);
+        // the OR / AND of all keys: how a sort planned on position chains finds its constant bytes (one atomic pair per workgroup)
+        atomicOr(&hist[HIST_TABLE_WORDS + HX_OR], s_red[1]);
+        atomicOr(&hist[HIST_TABLE_WORDS + HX_NAND], s_red[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sum of the slices.  Workgroup b < 256: top byte b — the 128 packed words of its 256 prefixes over all G slices (32 loads in
+// flight per thread; two thread groups take alternate slices) -> joint32[b][0..255], and, slice ranges being position
+// segments, T[x][b].  Workgroups 256 .. 256 + NCH - 1: digit-0 counts of position segment x -> the HIST region's table 0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hy_reduce_kernel(const uint32_t* __restrict__ slices, uint32_t G, uint32_t wg_per_seg,
+                                                         uint32_t* __restrict__ tab, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_lo[128], s_hi[128], s_T[NCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (blockIdx.x >= RADIX) {
+        const uint32_t x = blockIdx.x - RADIX;
+        uint32_t acc = 0;
+        for (uint32_t w = x * wg_per_seg; w < (x + 1u) * wg_per_seg && w < G; ++w) acc += slices[(size_t)w * HY_SLICE_WORDS + HY_JOINT_WORDS + tid];
+        hist[hist_index(0, tid, x)] = acc;
+        return;
+    }
+    const uint32_t b3 = blockIdx.x, w = tid & 127u, par = tid >> 7;  // (par is uniform per wave)
+    if (tid < 128) { s_lo[tid] = 0; s_hi[tid] = 0; }
+    if (tid < NCH) s_T[tid] = 0;
+    __syncthreads();
+    uint32_t lo = 0, hi = 0, cur_x = 0, acc_x = 0;
+    auto flush = [&]() {
+        const uint32_t t = wave_reduce_sum(acc_x);
+        if (lane == 0 && t != 0u) atomicAdd(&s_T[cur_x], t);
+        acc_x = 0;
+    };
+    constexpr uint32_t U = 32;
+    for (uint32_t s0 = par; s0 < G; s0 += 2u * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            const uint32_t s = s0 + 2u * k;
+            v[k] = slices[(size_t)(s < G ? s : G - 1u) * HY_SLICE_WORDS + b3 * 128u + w];  // unconditional on a clamped index, masked below
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            const uint32_t s = s0 + 2u * k;
+            if (s < G) {  // uniform
+                const uint32_t xs = s / wg_per_seg;
+                if (xs != cur_x) { flush(); cur_x = xs; }
+                lo += v[k] & 0xffffu;
+                hi += v[k] >> 16;
+                acc_x += (v[k] & 0xffffu) + (v[k] >> 16);
+            }
+        }
+    }
+    flush();
+    atomicAdd(&s_lo[w], lo);
+    atomicAdd(&s_hi[w], hi);
+    __syncthreads();
+    if (tid < 128) reinterpret_cast<uint2*>(tab + HYT_JOINT)[b3 * 128u + tid] = uint2{s_lo[tid], s_hi[tid]};
+    if (tid < NCH) tab[HYT_T + tid * RADIX + b3] = s_T[tid];
+}
+
+// ---------------------------------------------------------------------------
+// Scan + plan: one workgroup of 1024 threads, 64 prefixes per thread.
+//   cap       keys hy_local_sort_kernel's workgroup holds
+//   tile      keys per tile of passes A and B
+//   plan_bits bit 0: descending (pass B applies the reversal: it is the plan's last DigitBinningPass; hy_local_sort_kernel mirrors)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t* tab, uint32_t n, uint32_t seg_len0, uint32_t desc_stride,
+                                                        uint32_t cap, uint32_t tile) {
+    __shared__ uint32_t s_w[16], s_wmax[16], s_rw[4];
+    __shared__ uint32_t s_bstart[RADIX + 1], s_rowbase[RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* hist = slab + SLAB_HIST;
+    uint32_t val[64];
+    uint32_t sum = 0, mx = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint4 v = reinterpret_cast<const uint4*>(tab + HYT_JOINT)[tid * 16u + i];
+        val[4 * i] = v.x; val[4 * i + 1] = v.y; val[4 * i + 2] = v.z; val[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        sum += val[i];
+        mx = val[i] > mx ? val[i] : mx;
+    }
+    const uint32_t incl = wave_inclusive_scan_dpp(sum);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)mx, dd, 64);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) s_wmax[wave] = mx;
+    __syncthreads();
+    uint32_t excl = incl - sum, total = 0, maxb = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wave) excl += s_w[w];
+        total += s_w[w];
+        maxb = s_wmax[w] > maxb ? s_wmax[w] : maxb;
+    }
+    const bool valid = hist[HIST_TABLE_WORDS + HX_HY_BAD] == 0u && maxb <= cap && total == n;  // uniform
+    if (tid == 0) slab[SLAB_HY + HY_MAXBUCKET] = maxb;
+    if (!valid) {
+        // not this plan: the ordinary Scan kernel plans the LSD passes on position chains from the digit-0 counts of the same sweep
+        if (tid == 0) hist[HIST_TABLE_WORDS + HX_SKEW] = 1u;
+        return;
+    }
+    // bucket starts (exclusive prefix over the 16-bit prefixes); val[] becomes the prefix
+    {
+        uint32_t run = excl;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t c = val[i];
+            val[i] = run;
+            run += c;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            reinterpret_cast<uint4*>(tab + HYT_BASE)[tid * 16u + i] = uint4{val[4 * i], val[4 * i + 1], val[4 * i + 2], val[4 * i + 3]};
+        if (tid == 1023) tab[HYT_BASE + HY_BINS] = run;  // == n
+    }
+    if ((tid & 3u) == 0u) s_bstart[tid >> 2] = excl;
+    if (tid == 0) s_bstart[RADIX] = n;
+    __syncthreads();
+    uint32_t* info0 = slab + SLAB_INFO;
+    uint32_t* info1 = info0 + INFO_STRIDE;
+    uint32_t* desc0 = slab + SLAB_DESC;
+    uint32_t* desc1 = desc0 + desc_stride;
+    // ---- pass B: chain c = top-byte bucket c; a chain owns tiles + 1 descriptor rows
+    uint32_t rows = 0, rincl = 0;
+    if (tid < RADIX) {
+        rows = chain_tiles(s_bstart[tid], s_bstart[tid + 1], tile) + 1u;
+        rincl = wave_inclusive_scan_dpp(rows);
+        if (lane == 63) s_rw[wave] = rincl;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t rb = rincl - rows;
+        for (uint32_t w = 0; w < wave; ++w) rb += s_rw[w];
+        s_rowbase[tid] = rb;
+        info1[I_START + tid] = s_bstart[tid];
+        info1[I_END + tid] = s_bstart[tid + 1];
+        info1[I_ROW + tid] = rb;
+    }
+    __syncthreads();
+    {   // seed rows of pass B: digit d of chain c starts at the start of prefix (c, d)
+        const uint32_t c = tid >> 2, dq = (tid & 3u) * 64u;
+        uint4* row = reinterpret_cast<uint4*>(desc1 + (size_t)s_rowbase[c] * RADIX + dq);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            row[i] = uint4{(val[4 * i] << 2) | FLAG_INCLUSIVE, (val[4 * i + 1] << 2) | FLAG_INCLUSIVE, (val[4 * i + 2] << 2) | FLAG_INCLUSIVE,
+                           (val[4 * i + 3] << 2) | FLAG_INCLUSIVE};
+    }
+    // ---- pass A: the top byte over NCH position segments of the unsorted input (as the first pass of any sort)
+    if (tid < RADIX) {
+        uint32_t run = s_bstart[tid], rowa = 0;
+        for (uint32_t x = 0; x < NCH; ++x) {
+            const unsigned long long a = (unsigned long long)x * seg_len0, b = a + seg_len0;
+            const uint32_t s0 = a < n ? (uint32_t)a : n, s1 = b < n ? (uint32_t)b : n;
+            desc0[(size_t)rowa * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
+            run += tab[HYT_T + x * RADIX + tid];
+            if (tid == 0) {
+                info0[I_START + x] = s0;
+                info0[I_END + x] = s1;
+                info0[I_ROW + x] = rowa;
+            }
+            rowa += chain_tiles(s0, s1, tile) + 1u;
+        }
+    }
+    if (tid == 0) {
+        info0[PASS_FLAGS] = 0u;
+        info0[I_NCH] = NCH;
+        info0[I_NEXT_SHIFT] = 0xffffffffu;
+        info0[I_SHIFT] = 24u;
+        info0[I_MODE] = 0xffffffffu;
+        info1[PASS_FLAGS] = PF_SRC_ALT | PF_LAST;
+        info1[I_NCH] = CHMAX;
+        info1[I_NEXT_SHIFT] = 0xffffffffu;
+        info1[I_SHIFT] = 16u;
+        info1[I_MODE] = 0xffffffffu;
+        info0[2 * INFO_STRIDE + PASS_FLAGS] = PF_SKIP;  // the launches of LSD passes 2 and 3 have nothing to do
+        info0[3 * INFO_STRIDE + PASS_FLAGS] = PF_SKIP;
+        hist[HIST_TABLE_WORDS + HX_HY] = 1u;
+        slab[SLAB_HY + HY_VALID] = 1u;
+    }
+}
+static_assert(CHMAX == RADIX, "pass B: one chain per top-byte value");
+
+// ---------------------------------------------------------------------------
+// One workgroup per 16-bit prefix: the bucket's keys (all share their top 16 bits) sorted on the low 16 bits by two stable
+// 8-bit passes in LDS (the machinery of bucket_sort_kernel / small_sort_kernel), IN PLACE: the bucket is in registers before
+// anything is written, and no other workgroup touches its range.  Descending: pass B wrote to mirrored positions (index
+// n - 1 - o), so the bucket lies at [n - start - count, n - start) and is written back in reverse (keys only: equal keys
+// are indistinguishable, the reverse of the stable ascending order is any descending order).
+// ---------------------------------------------------------------------------
+template <int KT, int THREADS_, int KPT_>
+__global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slab,
+                                                                 uint32_t n, uint32_t descending) {
+    constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
+    constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
+    static_assert(THREADS >= RADIX && KPT % 2 == 0, "one digit per thread in the scans; ranks are packed two per register");
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
+    __shared__ uint32_t s_whist[WAVES * RADIX];
+    __shared__ uint32_t s_wtot[4];
+    if (__builtin_amdgcn_readfirstlane((int)slab[SLAB_HY + HY_VALID]) == 0) return;  // the sort runs on the LSD passes
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t start = tab[HYT_BASE + blockIdx.x], count = tab[HYT_BASE + blockIdx.x + 1u] - start;
+    if (count == 0u || count > TILE || start > n || count > n - start) return;  // (the last three cannot happen with a valid plan)
+    const uint32_t at = descending ? n - start - count : start;
+    const uint32_t kpt = (uint32_t)__builtin_amdgcn_readfirstlane((int)((count + THREADS - 1u) / THREADS));  // uniform, 1 .. KPT
+    const uint32_t my_base = wave * (64u * kpt) + lane;
+    uint32_t* whist = s_whist + wave * RADIX;
+    uint32_t key[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;  // uniform
+        const uint32_t slot = my_base + i * 64u;
+        key[i] = keys[at + (slot < count ? slot : count - 1u)];
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+        if ((uint32_t)i < kpt) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
+#pragma unroll 1
+    for (uint32_t shift = 0; shift < 16; shift += 8) {
+        for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
+        __syncthreads();
+        uint32_t off[KPT / 2];
+        mid_rank<1, KPT>(key, shift, my_base, count, whist, off, kpt);
+        __syncthreads();
+        uint32_t run = 0, scan_incl = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = s_whist[w * RADIX + tid];
+                s_whist[w * RADIX + tid] = run;
+                run += c;
+            }
+            scan_incl = wave_inclusive_scan_dpp(run);
+            if (lane == 63) s_wtot[wave] = scan_incl;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
+            const uint32_t dpre = wbase + scan_incl - run;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
+            const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
+            if (my_base + i * 64u < count) s_stage[lpos] = key[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
+            key[i] = s_stage[my_base + i * 64u];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t slot = my_base + i * 64u;
+        if ((uint32_t)i < kpt && slot < count) keys[at + (descending ? count - 1u - slot : slot)] = from_bits<KT>(key[i]);
+    }
+}
+
+}  // namespace gs

@@ -115,16 +115,21 @@ constexpr uint32_t FALLBACK_SPINS = GS_FALLBACK_SPINS;
 // planned on position chains, PF_POS) or group of the previous digit's values (NCH consecutive values per chain).  Every
 // chain is one contiguous range of the pass's input.
 constexpr uint32_t MAXCH = NCH;
+// Chain SLOTS of an info block / a pass's ticket row.  The LSD plans use NCH of them; the second pass of the two-level plan
+// (hybrid_kernels.hpp) runs on 256 chains — one per value of the top byte, whose bucket its input is already partitioned into.
+constexpr uint32_t CHMAX = 256;
+static_assert(CHMAX >= MAXCH && (CHMAX & (CHMAX - 1)) == 0, "chain slots");
 
-// per-pass info block (uint32 words), written by scan_kernel
-constexpr uint32_t I_START = 0;                // seg_start[MAXCH]
-constexpr uint32_t I_END = MAXCH;              // seg_end[MAXCH]
-constexpr uint32_t I_ROW = 2 * MAXCH;          // first descriptor row of each chain
-constexpr uint32_t PASS_FLAGS = 3 * MAXCH;     // PF_* bits
-constexpr uint32_t I_NCH = PASS_FLAGS + 1;     // chains in use (NCH or MAXCH)
+// per-pass info block (uint32 words), written by scan_kernel (or hy_scan_kernel)
+constexpr uint32_t I_START = 0;                // seg_start[CHMAX]
+constexpr uint32_t I_END = CHMAX;              // seg_end[CHMAX]
+constexpr uint32_t I_ROW = 2 * CHMAX;          // first descriptor row of each chain
+constexpr uint32_t PASS_FLAGS = 3 * CHMAX;     // PF_* bits
+constexpr uint32_t I_NCH = PASS_FLAGS + 1;     // chains in use (NCH, or CHMAX: a power of two)
 constexpr uint32_t I_NEXT_SHIFT = PASS_FLAGS + 2;  // PF_POS: bit position of the digit of the next pass that runs (this pass counts it per
                                                    // output position segment while it scatters), ~0 = nothing to count
 constexpr uint32_t I_SEGLOG = PASS_FLAGS + 3;      // PF_POS: log2 of the position segments of the passes behind the first one
+constexpr uint32_t I_SHIFT = PASS_FLAGS + 4;       // bit position of this pass's digit (launches with mode bit 7 take it from here: the plan is the device's)
 constexpr uint32_t I_MODE = PASS_FLAGS + 6;        // PF_SKEW passes: the most frequent value of this pass's digit
 constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 7 + 31) / 32) * 32;
 constexpr uint32_t PF_SKEW = 1;    // some digit holds > n/16 keys (GS_SKEW_SHIFT): rank with wave-aggregated adds
@@ -148,8 +153,8 @@ constexpr uint32_t PF_POS = 16;     // the sort runs on position chains in EVERY
 //  DESC      descriptors: pass q at DESC + q*desc_stride, rows of 256 words
 constexpr uint32_t SLAB_COUNTERS = 0;
 constexpr uint32_t COUNTER_STRIDE = 32;  // one 128-byte line per ticket counter: chains do not share a line
-constexpr uint32_t COUNTERS_PER_PASS = 72;  // >= MAXCH
-static_assert(COUNTERS_PER_PASS >= MAXCH, "ticket counters");
+constexpr uint32_t COUNTERS_PER_PASS = CHMAX + 8;
+static_assert(COUNTERS_PER_PASS >= CHMAX, "ticket counters");
 constexpr uint32_t MAX_PASSES = 8;  // 64-bit keys: one GlobalHistogram + Scan plans all eight passes (32-bit keys use the first four slots)
 constexpr uint32_t SLAB_STATUS = MAX_PASSES * COUNTERS_PER_PASS * COUNTER_STRIDE;
 constexpr uint32_t SLAB_INFO = SLAB_STATUS + 32;
@@ -160,6 +165,8 @@ constexpr uint32_t HX_SKEW = 0;  // a workgroup found the digit groups of its ke
 constexpr uint32_t HX_OR = 1;    // OR of the digit words of all keys (sortable form) ...
 constexpr uint32_t HX_NAND = 2;  // ... and of their complements: a bit set in both varies; a byte clear in their AND is constant — how a
                                  // sort planned on position chains (its joint tables are incomplete) still finds its identity passes
+constexpr uint32_t HX_HY = 3;    // two-level plan (hybrid_kernels.hpp): 1 = hy_scan_kernel found it valid and planned it — scan_kernel leaves the info blocks alone
+constexpr uint32_t HX_HY_BAD = 4;  // ... a histogram workgroup's packed 16-bit counters overflowed: the joint table is void
 constexpr uint32_t HIST_WORDS = HIST_TABLE_WORDS + 32;
 constexpr uint32_t SLAB_HSUB = SLAB_HIST + HIST_WORDS;
 constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
@@ -171,8 +178,11 @@ constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
 // arrival counter, the plan flags and the gather pass's unit geometry
 constexpr uint32_t SLAB_LS = SLAB_MID + SLAB_MID_WORDS;
 constexpr uint32_t SLAB_LS_WORDS = 1024;
-constexpr uint32_t SLAB_DESC = SLAB_LS + SLAB_LS_WORDS;
-static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_LS % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
+// HY: the two-level plan's words (hybrid_kernels.hpp): valid flag, largest bucket
+constexpr uint32_t SLAB_HY = SLAB_LS + SLAB_LS_WORDS;
+constexpr uint32_t SLAB_HY_WORDS = 32;
+constexpr uint32_t SLAB_DESC = SLAB_HY + SLAB_HY_WORDS;
+static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_LS % 4 == 0 && SLAB_HY % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif
@@ -755,6 +765,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
     // with the loads strung out behind each other it took 11 us.
     uint32_t hq[NCH], g_all[NPT], g = 0, gprev = 0;
     const uint32_t np = gridDim.x;  // passes of this plan
+    if (hist[HIST_TABLE_WORDS + HX_HY] != 0u) return;  // (uniform) the sort runs on the two-level plan: hy_scan_kernel has written every info block
     const uint32_t hx_skew = hist[HIST_TABLE_WORDS + HX_SKEW];
     {
         uint32_t h[NPT][NCH];
@@ -882,6 +893,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         const uint32_t later = run_mask & ~((2u << q) - 1u);
         my_info[I_NEXT_SHIFT] = (pos && later) ? 8u * (uint32_t)__builtin_ctz(later) : 0xffffffffu;
         my_info[I_SEGLOG] = seglog;
+        my_info[I_SHIFT] = 8u * q;
         my_info[I_MODE] = s_mode ? 255u - (uint32_t)(s_mode & 255u) : 0xffffffffu;
     }
     if (!counted) return;  // PF_POS behind the first pass: the pass's own workgroups derive skew flag, mode digit and seeds
@@ -971,9 +983,14 @@ __device__ __forceinline__ void binning_body(
                     on the last pass that runs (PF_LAST); bit2: zero the HIST region; bit4 / bit5: this launch is one of two
                     forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5); bit6: the
                     pass is also launched in its position-chain form — this launch works only if the plan's PF_POS matches its POS
-                    (checked first)*/) {
+                    (checked first); bit7: the digit's bit position comes from the info block (I_SHIFT), not from shift_full; bit8: the
+                    chain count comes from the info block BEFORE the first ticket (I_NCH may be CHMAX: the two-level plan's second pass) —
+                    sorts whose plan (LSD passes or the two-level plan) the Scan kernels choose on the device*/) {
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
+    if (mode & 128u) shift_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_SHIFT]);
+    // chain a workgroup asks first: blockIdx modulo the pass's chain count
+    const uint32_t chmask = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) - 1u : NCH - 1u;
     static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || VB == 4 || (VB == 8 && VR == 2))),
                   "the position-chain forms exist for 32-bit keys, keys-only, with 4-byte values (staged behind the keys) or with 8-byte values (two staging rounds), LDS-atomic ranking");
     using V = typename ValT<VB>::type;
@@ -988,6 +1005,10 @@ __device__ __forceinline__ void binning_body(
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
     static_assert(POS == 0 || PERSIST, "the position-chain forms keep state across their tiles");
+    // packed counters: two waves share a counter word and only the returning-atomic ranking adds to its own half (the ballot
+    // ranking stores whole words); the overflow guard of the packed next-digit table (0xC000 + TILE <= 0xFFFF) holds up to 16 384 keys
+    static_assert(!(Cfg::PACKED && RANK == 0), "packed per-wave counters need the LDS-atomic ranking");
+    static_assert(!Cfg::PACKED || Cfg::TILE <= 16384, "packed next-digit counters: a tile adds at most 16 384 to a 16-bit counter flushed at 0xC000");
     uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_raw);
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_raw + Cfg::STAGE_BYTES);
     constexpr bool PK = Cfg::PACKED;             // two 16-bit counters per word: per-wave rank counters and next-digit table
@@ -1090,7 +1111,7 @@ __device__ __forceinline__ void binning_body(
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
     // a chain is the start order, so every predecessor of a claimed tile is running.
     // Only when that chain is already fully claimed does thread 0 try the others. ----
-    uint32_t chain = blockIdx.x & (NCH - 1);
+    uint32_t chain = blockIdx.x & chmask;
     // geometry of the fast-path chain: requested before the ticket is (scalar loads that depend on blockIdx only), so
     // their round trip runs beside the ticket atomic's instead of after the barrier
     const uint32_t seg_start_f = info[I_START + chain], seg_end_f = info[I_END + chain], row_f = info[I_ROW + chain];
@@ -1132,7 +1153,36 @@ __device__ __forceinline__ void binning_body(
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
         __syncthreads();
-        if (wave == 0) {
+        if (nch > 64u) {
+            // More chains than a wave has lanes (the two-level plan's second pass: CHMAX chains, THREADS >= CHMAX): thread x looks at
+            // chain x; the open chain nearest to a per-workgroup starting point (Fibonacci hashing of the workgroup id: stealers
+            // spread over the open chains) is tried with one ticket, until a ticket holds or no chain is open.
+            const uint32_t start = ((blockIdx.x * 0x9E3779B1u) >> 16) & (nch - 1u);
+            for (;;) {
+                if (tid == 0) s_misc[0] = 0xffffffffu;
+                __syncthreads();
+                if (tid < nch) {
+                    const uint32_t tx = chain_tiles(info[I_START + tid], info[I_END + tid], TILE);
+                    if (ld_agent(&counters[tid * COUNTER_STRIDE]) < tx) atomicMin(&s_misc[0], (((tid - start) & (nch - 1u)) << 16) | tid);
+                }
+                __syncthreads();
+                const uint32_t cand = uni(s_misc[0]);
+                if (cand == 0xffffffffu) {  // every chain is fully claimed
+                    if (tid == 0) s_misc[1] = 0xffffffffu;
+                    break;
+                }
+                const uint32_t x = cand & 0xffffu;
+                if (tid == 0) {
+                    const uint32_t t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                    s_misc[1] = t < chain_tiles(info[I_START + x], info[I_END + x], TILE) ? t : 0xffffffffu;
+                }
+                __syncthreads();
+                if (uni(s_misc[1]) != 0xffffffffu) {
+                    if (tid == 0) s_misc[0] = x;
+                    break;
+                }
+            }
+        } else if (wave == 0) {
             uint32_t tiles_x = 0;
             bool open = false;
             if (lane < nch) {

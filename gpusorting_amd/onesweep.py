@@ -171,10 +171,16 @@ class OneSweep:
         """Identity passes (one digit value for all keys) are dropped in pairs on the device (default on)."""
         check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")
 
-    def set_plan(self, local_sort) -> None:
-        """Large keys-only sorts of 32-bit keys: 1 / True the local-sort plan (ls_kernels.hpp), 0 / False the GlobalHistogram / Scan /
-        4-pass pipeline (default), 2 the local-sort plan at every size of the general path (tests)."""
-        check(self._lib.gs_onesweep_set_plan(self._h, int(local_sort)), "gs_onesweep_set_plan")
+    def set_plan(self, plan) -> None:
+        """Large keys-only sorts of 32-bit keys: 0 the library picks (two-level plan from 2^26 + 1 keys up when the device finds the
+        keys near-uniform, LSD passes otherwise), 1 the four LSD passes only, 2 the two-level plan wherever it can run (tests)."""
+        check(self._lib.gs_onesweep_set_plan(self._h, int(plan)), "gs_onesweep_set_plan")
+
+    def last_plan(self) -> dict:
+        """What the device decided for the last sort (synchronises): {'two_level': bool, 'largest_bucket': int}."""
+        p, b = C.c_uint32(0), C.c_uint32(0)
+        check(self._lib.gs_onesweep_last_plan(self._h, C.byref(p), C.byref(b), _stream_ptr()), "gs_onesweep_last_plan")
+        return {"two_level": bool(p.value), "largest_bucket": int(b.value)}
 
     @property
     def key_bytes(self) -> int:
@@ -245,6 +251,14 @@ class OneSweep:
         out = (C.c_uint32 * 1024)()
         check(self._lib.gs_onesweep_global_histogram(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()),
               "gs_onesweep_global_histogram")
+        return np.frombuffer(out, dtype=np.uint32).reshape(4, 256).copy()
+
+    def scan_rows(self, keys: torch.Tensor, n: int | None = None) -> np.ndarray:
+        """GlobalHistogram + Scan; the raw first descriptor row of each of the four passes: (digit start << 2) | 2."""
+        n = keys.numel() if n is None else int(n)
+        _require_room(keys, n, "keys")
+        out = (C.c_uint32 * 1024)()
+        check(self._lib.gs_onesweep_scan(self._h, keys.data_ptr(), n, self.key_type, out, _stream_ptr()), "gs_onesweep_scan")
         return np.frombuffer(out, dtype=np.uint32).reshape(4, 256).copy()
 
     def digit_pass(self, keys_in: torch.Tensor, keys_out: torch.Tensor, pass_index: int, n: int | None = None,

@@ -97,7 +97,8 @@ typedef struct gs_onesweep_options {
                                         groups uneven, 0 never, 2 always (tests, tuning) */
     uint32_t position_chains_min_log2;  /* ... from 2^this + 1 keys up (default 25; 20 .. 30) */
     int32_t key64_sweeps;            /* 64-bit keys: 1 (default) one histogram sweep plans all eight passes, 2 one sweep per word */
-    int32_t plan;                    /* gs_onesweep_set_plan: 0 (default), 1 local-sort plan, 2 local-sort plan at every size */
+    int32_t plan;                    /* gs_onesweep_set_plan: 0 (default) the library picks — the two-level plan for large keys-only sorts whose
+                                        keys turn out near-uniform, the four LSD passes otherwise; 1 LSD passes only; 2 two-level plan wherever it can run */
     int32_t first_pass_big;          /* 1 (default): keys-only mid sizes run their first pass on the 16 384-key tile */
     uint32_t hist_blocks;            /* workgroups of the GlobalHistogram kernel; 0 (default) = one per CU (tuning aid) */
     uint32_t debug_flags;            /* tuning builds: extra mode bits handed to the kernels (tools/r04_ls_*.py); 0 */
@@ -107,7 +108,8 @@ void gs_onesweep_options_default(gs_onesweep_options* o);
  * shape it was not built with, or a value out of range. */
 gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mode, uint32_t value_bytes, const gs_onesweep_options* options);
 
-/* Bytes of device memory a handle for max_keys allocates (descriptors + histograms). */
+/* Bytes of device memory a handle for max_keys allocates (descriptors + histograms + the two-level plan's tables): an upper
+ * bound over modes and options (default hist_blocks). */
 size_t gs_onesweep_temp_bytes(uint32_t max_keys);
 /* Keys per binning tile of this build (the reference's k_partitionSize = 7680,
  * OneSweepDispatcher.cuh:23; tests ladder sizes over [P, 2P]). */
@@ -174,16 +176,21 @@ gs_status gs_onesweep_set_mid_path(gs_onesweep* h, int on);
  * four passes).  Results are identical either way; 0 runs all four passes.  Default 1;
  * (gs_onesweep_options::skip_passes at create). */
 gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
-/* Plan of large keys-only sorts of 32-bit keys (n > 2^25, library-picked shape, rank mode 1).  1: the LOCAL-SORT plan —
- * the reference's GlobalHistogram + Scan + first DigitBinningPass (GPUSortingCUDA/Sort/OneSweep.cu:44-162 and the first of
- * :164-344) become ONE kernel that sorts every 16 384-key tile locally by digit 0 and writes it back in place (sequential
- * stores, no look-back) with a run table; the second pass gathers the runs in (digit, tile) order — which is the first pass's
- * stable output order — and every pass counts the next pass's histogram while it scatters: 32 bytes of HBM traffic per key
- * instead of 36.  0 (default): the GlobalHistogram / Scan / 4 x DigitBinningPass pipeline.  2 (tests): the local-sort plan at
- * EVERY size the general path would take.  The result is bit-identical either way; profiles/r04_ls_plan_status.txt holds what each
- * kernel of the plan costs today and why it is not the default.  GS_ERR_MODE: the handle has no tables for the plan (pairs, or
- * max_keys <= 2^25). */
-gs_status gs_onesweep_set_plan(gs_onesweep* h, int local_sort);
+/* Plan of large keys-only sorts of 32-bit keys (library-picked shape, rank mode 1, position chains allowed).
+ * The reference's pipeline is GlobalHistogram + Scan + four 8-bit LSD DigitBinningPasses (GPUSortingCUDA/Sort/OneSweep.cu:44-344,
+ * dispatch OneSweepDispatcher.cuh:311-336): 36 bytes of memory traffic per key.  The TWO-LEVEL plan (hybrid_kernels.hpp) runs the same
+ * kernels in another order — one histogram sweep over the keys' top 16 bits, a Scan, a DigitBinningPass on the top byte, a
+ * DigitBinningPass on byte 2 inside the top-byte buckets (256 chains), then one workgroup per 16-bit-prefix bucket sorts the low
+ * 16 bits in LDS, in place: 28 bytes per key, the same result bit for bit.  It needs buckets that fit a workgroup (near-uniform top
+ * 16 bits); whether they do is decided ON THE DEVICE from the histogram (no host round trip): otherwise the same launches run the
+ * four LSD passes on position chains.
+ *   0 (default): the two-level plan is offered from 2^26 + 1 keys up;  1: never (the LSD passes only);  2 (tests): offered at every
+ *   size from gs_onesweep_options::position_chains_min_log2 up.  GS_ERR_MODE for 2 on a handle without the plan's tables (pairs,
+ *   max_keys <= 2^20, or created with plan 1).
+ * gs_onesweep_last_plan (synchronous) reports what the device decided for the last sort: *plan = 1 the two-level plan ran, 0 the LSD
+ * passes (or a one- / two-launch route); *largest_bucket (may be NULL) = the largest 16-bit-prefix bucket it saw (0 if not offered). */
+gs_status gs_onesweep_set_plan(gs_onesweep* h, int plan);
+gs_status gs_onesweep_last_plan(gs_onesweep* h, uint32_t* plan, uint32_t* largest_bucket, void* stream);
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
@@ -211,6 +218,12 @@ gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count
  * host.  Synchronous. */
 gs_status gs_onesweep_global_histogram(gs_onesweep* h, const void* d_keys, uint32_t n,
                                        gs_key_type key_type, uint32_t* h_hist, void* stream);
+/* GlobalHistogram + Scan, and what the Scan kernel left for the passes (GPUSortingCUDA/Sort/OneSweep.cu:125-162, the
+ * store of :141-158): h_rows[q * 256 + d] = the RAW descriptor word of digit d in the first row of pass q, which is
+ * (exclusive prefix of histogram q at d) << 2 | FLAG_INCLUSIVE (2) — the reference's passHistogram_q[d] before any tile has run.
+ * Synchronous.  (The direct parity check of row A2 of SURVEY.md 8a: tests diff it against the CPU restatement of the reference's Scan.) */
+gs_status gs_onesweep_scan(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type key_type, uint32_t* h_rows,
+                           void* stream);
 /* One stable DigitBinningPass (OneSweep.cu:164-344 / :346-600) on byte `pass`
  * (0..3) from d_keys_in to d_keys_out (values optional, NULL for keys-only).
  * reverse_index != 0 applies the reference's descending rule to this pass.

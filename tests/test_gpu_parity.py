@@ -151,6 +151,20 @@ def test_global_histogram_parity(gpu, oracle, kt):
         np.testing.assert_array_equal(h, oracle.global_histogram(keys, kt), err_msg=f"n={n}")
 
 
+@pytest.mark.parametrize("kt", [0, 1, 2])
+def test_scan_digit_starts_parity(gpu, oracle, kt):
+    """SURVEY.md 8a row A2, directly: the digit starts the Scan kernel leaves in the first descriptor row of each pass, read back
+    and diffed against the oracle's restatement of the reference's Scan (GPUSortingCUDA/Sort/OneSweep.cu:125-162; the store of
+    :141-158 is (exclusive prefix << 2) | FLAG_INCLUSIVE).  Uniform and skewed keys, sizes on both sides of the tile borders."""
+    for n, andc in ((1, 0), (5, 0), (1023, 0), (65536, 0), (65539, 2), ((1 << 22) + 1, 0), ((1 << 24) + 3, 4)):
+        keys = oracle.init_random(n, n + 7, andc)
+        s = gpu.OneSweep(n, key_type=kt)
+        rows = s.scan_rows(to_dev(keys))
+        s.close()
+        assert ((rows & 3) == 2).all(), f"n={n}: a seed row is not INCLUSIVE"
+        np.testing.assert_array_equal(rows >> 2, oracle.scan(oracle.global_histogram(keys, kt)).reshape(4, 256), err_msg=f"n={n}")
+
+
 @pytest.mark.parametrize("vb", [0, 4, 8])
 def test_each_digit_pass_parity(gpu, oracle, P, vb):
     import torch

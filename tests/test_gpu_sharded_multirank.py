@@ -32,7 +32,7 @@ def _worker(rank, world, port, shard, andc, pairs, q):
         g.init_random(pick, 99 + rank, 0)
         heavy = (pick.to(torch.int64) & 0xFFFFFFFF) % 10 != 0
         keys = torch.where(heavy, (keys & 0x00FFFFFF) | 0x5A000000, keys).contiguous()
-        slack = 1.25
+        slack = 1.25 if world <= 4 else 1.5   # (world 8: whole 1/16ths of the heavy byte, 5.6 % of all keys each, against a share of 12.5 %)
     else:
         g.init_random(keys, 10 + 1000 * rank, andc)
     vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
@@ -54,8 +54,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
+# world 8 (BASELINE.json configs[3]'s world size) on ONE GPU: eight ranks time-share cuda:0 over the host-staged transport
 @pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (1 << 20) + 77), (3, 0, True, 300001), (2, 1, True, (1 << 18) + 5),
-                                                    (2, -1, False, (1 << 19) + 9), (3, -1, True, 200003)])
+                                                    (2, -1, False, (1 << 19) + 9), (3, -1, True, 200003),
+                                                    (8, 0, False, (1 << 18) + 11), (8, 0, True, (1 << 18) + 3), (8, -1, True, 150001)])
 def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -63,9 +65,9 @@ def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
     procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    got = sorted((q.get(timeout=480) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
     all_keys = np.concatenate([x[1] for x in got])
     out_keys = np.concatenate([x[3] for x in got])

@@ -1,0 +1,171 @@
+"""GPU parity tests (-m gpu) of the TWO-LEVEL plan (gpusorting_amd/csrc/hybrid_kernels.hpp; gs_onesweep_set_plan): one histogram
+sweep over the keys' top 16 bits, a DigitBinningPass on the top byte, one on byte 2 inside the top-byte buckets (256 chains), and a
+bucket-local sort of the low 16 bits in LDS — against the CPU oracle, bit-exact, and against the four LSD passes.  The device
+decides per sort whether the plan applies (gs_onesweep_last_plan); keys it does not apply to must come out exact all the same,
+through the LSD passes on position chains.  Plan 2 offers it at every size from 2^20 keys (position_chains_min_log2 = 20).
+
+Reference behaviour: GPUSortingCUDA/Sort/OneSweep.cu:44-344 (histogram, scan, four stable 8-bit passes); key types and descending
+order: GPUSortingD3D12/Shaders/SortCommon.hlsl:134-154,594-597."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAXK = (1 << 25) + 4096
+
+
+def to_dev(a):
+    import torch
+    return torch.from_numpy(a.view(np.int32)).cuda()
+
+
+@pytest.fixture(scope="module")
+def sorters(gpu):
+    made = {}
+
+    def get(kt, order):
+        if (kt, order) not in made:
+            made[(kt, order)] = gpu.OneSweep(MAXK, order, kt, small_path=0, mid_path=0, plan=2, position_chains_min_log2=20)
+        return made[(kt, order)]
+    yield get
+    for s in made.values():
+        s.close()
+
+
+def _keys(oracle, n, seed, andc, kind):
+    k = oracle.init_random(n, seed, andc, 0)
+    if kind == "low16":        # one 16-bit prefix holds everything: the plan cannot apply
+        k &= np.uint32(0xFFFF)
+    elif kind == "high16":     # every bucket's keys are equal in their low 16 bits
+        k &= np.uint32(0xFFFF0000)
+    elif kind == "const":
+        k[:] = 0xDEADBEEF
+    elif kind == "sorted":
+        k.sort()
+    elif kind == "reversed":
+        k[::-1].sort()
+    elif kind == "blocks":      # long stretches of one top byte: whole tiles of pass A rank on one counter
+        k = (k & np.uint32(0x00FFFFFF)) | (((np.arange(n, dtype=np.uint32) // 40000) & np.uint32(0xFF)) << np.uint32(24))
+    elif kind == "top8":        # few top bytes in use, byte 2 uniform: 8 chains of pass B carry everything
+        k = (k & np.uint32(0x07FFFFFF)) | ((k & np.uint32(7)) << np.uint32(29))
+    elif kind == "bigbucket":   # uniform but for ONE 16-bit prefix that holds 1 % of the keys: above any workgroup's capacity
+        k = np.where(k % 100 == 0, (k & np.uint32(0xFFFF)) | np.uint32(0x12340000), k).astype(np.uint32)
+    return k
+
+
+@pytest.mark.parametrize("n", [(1 << 20), (1 << 20) + 7, 3 * 16384 * 37, (1 << 22) + 12345, (1 << 24) - 1])
+@pytest.mark.parametrize("kt,order", [(0, 0), (0, 1), (1, 0), (2, 1)])
+def test_two_level_plan_sizes_types_orders(gpu, oracle, sorters, n, kt, order):
+    s = sorters(kt, order)
+    k = _keys(oracle, n, n & 0xFFFF | 1, 0, "uniform")
+    if kt == 2:
+        k = np.where((k & 0x7F800000) == 0x7F800000, k & ~np.uint32(0x00800000), k).astype(np.uint32)  # (NaN patterns sort by bits in both)
+    want = oracle.std_sort(k, kt, order)
+    for plan in (2, 1):
+        s.set_plan(plan)
+        dk = to_dev(k.copy())
+        s.sort(dk)
+        s.check()
+        assert s.last_plan()["two_level"] == (plan == 2)
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), want, err_msg=f"plan {plan}")
+        r = s.check_state()
+        assert r["rows_not_inclusive"] == 0 and r["rows_not_monotone"] == 0 and r["chains_short_of_tickets"] == 0 and r["hist_words_nonzero"] == 0, r
+        if plan == 2:
+            assert r["keys_per_pass"][:2] == [n, n] and sum(r["keys_per_pass"]) == 2 * n, r   # pass A, pass B; LSD passes 2 and 3 did not run
+
+
+@pytest.mark.parametrize("kind,andc,two_level", [("uniform", 0, True), ("uniform", 1, False), ("uniform", 2, False), ("uniform", 4, False),
+                                                 ("low16", 0, False), ("high16", 0, True), ("const", 0, False), ("sorted", 0, True),
+                                                 ("reversed", 0, True), ("blocks", 0, True), ("top8", 0, True), ("bigbucket", 0, False)])
+def test_two_level_plan_distributions(gpu, oracle, sorters, kind, andc, two_level):
+    """Whatever the keys look like the result is exact; WHICH plan ran is the device's decision, checked against what the
+    distribution implies (a bucket above the local sort's capacity -> the LSD passes on position chains)."""
+    n = (1 << 22) + 12345
+    k = _keys(oracle, n, 77, andc, kind)
+    for order in (0, 1):
+        s = sorters(0, order)
+        s.set_plan(2)
+        want = oracle.std_sort(k, 0, order)
+        dk = to_dev(k.copy())
+        s.sort(dk)
+        s.check()
+        lp = s.last_plan()
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), want)
+        assert lp["two_level"] == two_level, (kind, andc, lp)
+
+
+def test_two_level_plan_back_to_back_with_other_plans(gpu, oracle, sorters):
+    """Sorts in a row on one handle — uniform (two-level), skewed (falls back), LSD-only, uniform again: the slices, tables and slab
+    regions are reused and every sort starts from a clean state."""
+    import torch
+    n = (1 << 25) + 4095
+    s = sorters(0, 0)
+    for rep, (andc, plan, two_level) in enumerate([(0, 2, True), (3, 2, False), (0, 1, False), (0, 2, True), (0, 0, False)]):
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, 10 + rep, andc)
+        k = dk.cpu().numpy().view(np.uint32)
+        s.set_plan(plan)
+        s.sort(dk)
+        s.check()
+        assert s.last_plan()["two_level"] == two_level, (rep, s.last_plan())   # (plan 0 offers it from 2^26 + 1 keys only)
+        assert gpu.validate(dk) == 0
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), np.sort(k))
+
+
+def test_two_level_plan_needs_its_tables(gpu):
+    s = gpu.OneSweep(1 << 20)
+    with pytest.raises(Exception):
+        s.set_plan(2)      # max_keys <= 2^20: the handle has no tables for the plan
+    s.set_plan(0)
+    s.set_plan(1)
+    s.close()
+    p = gpu.OneSweep(MAXK, mode=gpu.MODE_PAIRS, value_bytes=4)
+    with pytest.raises(Exception):
+        p.set_plan(2)      # pairs
+    p.close()
+
+
+def test_two_level_plan_in_a_hip_graph(gpu, oracle, sorters):
+    """No host round trip inside the plan: captured once, replayed on new keys — uniform keys run the two-level plan, skewed keys the
+    LSD passes, from the SAME captured launches."""
+    import torch
+    n = (1 << 21) + 999
+    s = sorters(0, 0)
+    s.set_plan(2)
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    alt = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, 5, 0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s.sort(dk, alt_keys=alt)  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s.sort(dk, alt_keys=alt)
+    for seed, andc, two_level in ((6, 0, True), (7, 3, False), (8, 0, True)):
+        gpu.init_random(dk, seed, andc)
+        torch.cuda.synchronize()
+        k = dk.cpu().numpy().view(np.uint32)
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), np.sort(k))
+        assert s.last_plan()["two_level"] == two_level
+    s.check()
+
+
+def test_two_level_plan_default_threshold_and_2pow27(gpu, oracle):
+    """Plan 0 (the default): offered above 2^26 keys — 2^27 uniform keys run it, exact against the oracle's parallel sort."""
+    import torch
+    n = 1 << 27
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, 27, 0)
+    keys = dk.cpu().numpy().view(np.uint32)
+    s = gpu.OneSweep(n)
+    s.sort(dk)
+    s.check()
+    assert s.last_plan()["two_level"]
+    ref = oracle.std_sort_parallel(keys, oracle.hardware_threads())
+    assert bool((dk == torch.from_numpy(ref.view(np.int32)).cuda()).all().item())
+    s.close()

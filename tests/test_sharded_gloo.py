@@ -84,7 +84,9 @@ def _worker(rank, world, port, shard, andc, pairs, q):
         keys = o.init_random(shard, 10 + 1000 * rank, 0)
         heavy = o.init_random(shard, 99 + rank, 0) % np.uint32(10) != 0
         keys = np.where(heavy, (keys & np.uint32(0x00FFFFFF)) | np.uint32(0x5A000000), keys).astype(np.uint32)
-        slack = 1.25
+        # (the 12-bit split moves whole 1/16ths of the heavy byte — 5.6 % of all keys each: at world 8 a rank's share of 12.5 %
+        #  is two or three of them, so the best split leaves buckets of up to 16.9 %: capacity 1.5 x the shard)
+        slack = 1.25 if world <= 4 else 1.5
     else:
         keys = o.init_random(shard, 10 + 1000 * rank, andc)
     vals = (np.arange(shard, dtype=np.uint32) + np.uint32(rank * shard)) if pairs else None
@@ -94,7 +96,7 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     bk, bv, nb = s.sort(tk, values=tv)
     assert s.last_split == ("12-bit prefix" if andc < 0 else "top byte"), s.last_split
     if andc < 0:
-        assert nb <= s.capacity and abs(nb - shard) < 0.2 * shard, (nb, shard)   # balanced after all
+        assert nb <= s.capacity and abs(nb - shard) < (0.2 if world <= 4 else 0.45) * shard, (nb, shard)   # balanced after all
     q.put((rank, keys, vals, bk.numpy().view(np.uint32).copy(), None if bv is None else bv.numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -106,8 +108,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
+# world 8 = the world size BASELINE.json configs[3] names: 7 peers per rank, 8-way count / displacement tables, the 12-bit split
 @pytest.mark.parametrize("world,andc,pairs", [(2, 0, False), (2, 0, True), (3, 0, False), (2, 2, True),
-                                              (2, -1, False), (3, -1, True)])   # -1: skewed top byte -> 12-bit split
+                                              (2, -1, False), (3, -1, True),   # -1: skewed top byte -> 12-bit split
+                                              (8, 0, False), (8, 2, True), (8, -1, True)])
 def test_sharded_sort_gloo(world, andc, pairs):
     shard = 20011
     ctx = mp.get_context("spawn")
@@ -116,9 +120,9 @@ def test_sharded_sort_gloo(world, andc, pairs):
     procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     all_keys = np.concatenate([g[1] for g in got])
     out_keys = np.concatenate([g[3] for g in got])

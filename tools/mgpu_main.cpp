@@ -10,6 +10,11 @@
 //                   passed in memory; every thread calls gs_mgpu_create = ncclCommInitRank concurrently)
 //   --one-device    every rank on device 0 with world = 1 each is NOT a multi-rank run; with --gpus 1 the exchange path is
 //                   forced (gs_mgpu_set_force_exchange) so that the whole pipeline runs on a one-GPU box
+//   --ranks N --share-gpu   a REHEARSAL of world = N on ONE GPU: N rank threads time-share device 0 and exchange through an
+//                   in-process transport (gs_mgpu_create_with_transport: every collective is a barrier + device-to-device copies; RCCL
+//                   refuses several ranks on one device).  Everything else is the product pipeline at the real world size — N-way
+//                   plan, count and displacement tables, N - 1 peers per rank, the closing status gather.  The throughput it prints is
+//                   that of N ranks sharing one GPU's HBM, not a scaling number.
 // Every rank generates its shard with the library's InitRandom (seed 10 + i + 1000 * rank: bench.py's convention), sorts K
 // times (weak scaling: 2^L keys per GPU), checks its bucket (sorted; sizes add up; bucket borders ascend across ranks) and
 // reports its phase times; rank 0 prints ONE JSON line: GKeys/s of the whole job (slowest rank), per-phase ms (max over
@@ -20,10 +25,12 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,8 +42,62 @@ namespace {
 struct Options {
     int gpus = 1, log2 = 28, iters = 5, warmup = 1, pairs = 0, preset = 0;
     double slack = 1.25;
-    bool threads = false, one_device = false;
+    bool threads = false, one_device = false, share_gpu = false;
 };
+
+// ---- in-process transport of --share-gpu: all ranks are threads of this process on device 0 ----
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, waiting = 0;
+    unsigned long long gen = 0;
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        const unsigned long long g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(l, [&] { return gen != g; });
+    }
+};
+struct Bus {
+    struct Pub { const void* send[2]; const uint32_t* send_displs; };
+    Barrier bar;
+    std::vector<Pub> pub;
+};
+struct BusRank { Bus* bus; uint32_t rank, world; };
+int bus_all_gather(void* user, const void* d_send, void* d_recv, size_t count, void* stream) {
+    BusRank* r = static_cast<BusRank*>(user);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = hipStreamSynchronize(s) == hipSuccess ? 0 : 1;  // what this rank sends is complete
+    r->bus->pub[r->rank].send[0] = d_send;
+    r->bus->bar.wait();
+    for (uint32_t p = 0; p < r->world; ++p)
+        if (hipMemcpyAsync(static_cast<char*>(d_recv) + (size_t)p * count * 4, r->bus->pub[p].send[0], count * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+    r->bus->bar.wait();  // nobody reuses its send buffer before everybody has read it
+    return rc;
+}
+int bus_exchange(void* user, uint32_t n_arrays, const void* const* d_send, void* const* d_recv, const uint32_t* elem_bytes,
+                 const uint32_t* send_counts, const uint32_t* send_displs, const uint32_t* recv_counts, const uint32_t* recv_displs, void* stream) {
+    (void)send_counts;
+    BusRank* r = static_cast<BusRank*>(user);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+    Bus::Pub& mine = r->bus->pub[r->rank];
+    for (uint32_t a = 0; a < n_arrays && a < 2; ++a) mine.send[a] = d_send[a];
+    mine.send_displs = send_displs;
+    r->bus->bar.wait();
+    for (uint32_t a = 0; a < n_arrays && a < 2; ++a)
+        for (uint32_t p = 0; p < r->world; ++p) {  // peer p's elements for this rank start at ITS send_displs[this rank]
+            const Bus::Pub& pp = r->bus->pub[p];
+            if (recv_counts[p] && hipMemcpyAsync(static_cast<char*>(d_recv[a]) + (size_t)recv_displs[p] * elem_bytes[a],
+                                                 static_cast<const char*>(pp.send[a]) + (size_t)pp.send_displs[r->rank] * elem_bytes[a],
+                                                 (size_t)recv_counts[p] * elem_bytes[a], hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
+        }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+    r->bus->bar.wait();
+    return rc;
+}
+Bus g_bus;
 
 struct RankResult {  // what a rank reports to rank 0 (plain data: crosses a pipe in fork mode)
     double ms_total = 0;            // mean wall time per sort (host clock around K sorts + sync)
@@ -65,11 +126,16 @@ struct RankResult {  // what a rank reports to rank 0 (plain data: crosses a pip
     } while (0)
 
 int run_rank(const Options& o, int rank, const uint8_t* id, RankResult* out) {
-    CHECK_HIP(hipSetDevice(o.one_device ? 0 : rank));
+    CHECK_HIP(hipSetDevice((o.one_device || o.share_gpu) ? 0 : rank));
     const uint32_t n = 1u << o.log2;
     const uint32_t cap = (uint32_t)std::min<double>((double)n * o.slack + 256.0, (double)GS_MAX_KEYS);
     const uint32_t vb = (uint32_t)o.pairs;
     gs_mgpu* ctx = nullptr;
+    BusRank bus_rank{&g_bus, (uint32_t)rank, (uint32_t)o.gpus};
+    if (o.share_gpu) {
+        const gs_mgpu_transport t{&bus_rank, bus_all_gather, bus_exchange};
+        CHECK_GS(gs_mgpu_create_with_transport(&ctx, &t, (uint32_t)rank, (uint32_t)o.gpus, n, cap, vb ? GS_MODE_PAIRS : GS_MODE_KEYS_ONLY, vb));
+    } else
     CHECK_GS(gs_mgpu_create(&ctx, id, (uint32_t)rank, (uint32_t)o.gpus, n, cap, vb ? GS_MODE_PAIRS : GS_MODE_KEYS_ONLY, vb));
     if (o.gpus == 1) CHECK_GS(gs_mgpu_set_force_exchange(ctx, 1));  // a one-GPU box still runs split + exchange + sort
     hipStream_t s;
@@ -159,7 +225,7 @@ void report(const Options& o, const std::vector<RankResult>& r, const std::vecto
            "\"local_sort_rank0\": {\"per_kernel_ms\": {\"global_histogram\": %.4f, \"scan\": %.4f, \"pass0\": %.4f, \"pass1\": %.4f, "
            "\"pass2\": %.4f, \"pass3\": %.4f, \"total\": %.4f}, \"roofline\": {\"bound\": \"hbm\", \"kernel\": \"one 8-bit DigitBinningPass\", "
            "\"achieved\": %.1f, \"peak\": 8000.0, \"unit\": \"GB/s\", \"frac\": %.4f}}, \"rank_exit_codes\": [",
-           n * W / (ms * 1e-3) / 1e9, W, o.threads ? "threads" : "fork", n, o.pairs, o.iters, ms, ok ? "true" : "false", ph[0], ph[1], ph[2],
+           n * W / (ms * 1e-3) / 1e9, W, o.share_gpu ? "threads sharing ONE GPU over an in-process transport (rehearsal, not a scaling number)" : o.threads ? "threads" : "fork", n, o.pairs, o.iters, ms, ok ? "true" : "false", ph[0], ph[1], ph[2],
            ph[3], (unsigned long long)sent_max, (unsigned long long)sent_sum, ex_gbs, ex_gbs / links, W - 1, ex_gbs / links / 153.0, r[0].fine ? "12-bit prefix" : "top byte",
            r[0].kern[1], r[0].kern[2], r[0].kern[3], r[0].kern[4], r[0].kern[5], r[0].kern[6], r[0].kern[7], pass_gbs, pass_gbs / 8000.0);
     for (int i = 0; i < W; ++i) printf("%s%d", i ? ", " : "", rc[i]);
@@ -182,6 +248,8 @@ int main(int argc, char** argv) {
         else if (a == "--slack") o.slack = i + 1 < argc ? atof(argv[++i]) : 1.25;
         else if (a == "--mode") o.threads = i + 1 < argc && std::string(argv[++i]) == "threads";
         else if (a == "--one-device") o.one_device = true;
+        else if (a == "--ranks") o.gpus = val(1);
+        else if (a == "--share-gpu") { o.share_gpu = true; o.threads = true; }
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (o.gpus < 1 || o.gpus > 64 || o.log2 < 10 || o.log2 > 29 || (o.pairs != 0 && o.pairs != 4 && o.pairs != 8)) {
@@ -190,10 +258,14 @@ int main(int argc, char** argv) {
     }
     std::vector<RankResult> res(o.gpus);
     std::vector<int> rc(o.gpus, 0);
+    if (o.share_gpu) {
+        g_bus.bar.n = o.gpus;
+        g_bus.pub.resize(o.gpus);
+    }
     if (o.threads) {
         // one process: rank 0's id in memory, every thread = one rank (gs_mgpu_create calls ncclCommInitRank concurrently)
-        uint8_t id[GS_MGPU_UNIQUE_ID_BYTES];
-        if (hipSetDevice(0) != hipSuccess || gs_mgpu_get_unique_id(id) != GS_OK) {
+        uint8_t id[GS_MGPU_UNIQUE_ID_BYTES] = {0};
+        if (hipSetDevice(0) != hipSuccess || (!o.share_gpu && gs_mgpu_get_unique_id(id) != GS_OK)) {
             fprintf(stderr, "gs_mgpu_get_unique_id failed (rccl %d)\n", gs_last_rccl_error());
             return 3;
         }
