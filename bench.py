@@ -91,28 +91,40 @@ def cpu_baseline(log2n: int):
     }
 
 
-def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys):
-    """HBM bytes per DigitBinningPass launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
-    separate rocprofv3 --pmc passes of this same command and committed under profiles/) — a BORROWED number: it was
-    measured by the builder's rocprofv3 runs, not by this run, and the block says so.  None if the committed
-    measurement is for another workload/tile shape."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            break
-    else:
-        return None
+KERNEL_SOURCES = ("gpusorting_amd/csrc/onesweep_kernels.hpp", "gpusorting_amd/csrc/hybrid_kernels.hpp", "gpusorting_amd/csrc/gpusort_capi.hip")
+
+
+def kernel_sources_sha256() -> str:
+    """One hash over the files the kernels and their launches are compiled from: what a committed counter measurement is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys, kernel="pass"):
+    """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate rocprofv3 --pmc
+    passes of this same command and committed under profiles/) — a BORROWED number: measured by the builder's rocprofv3 runs, not
+    by this run.  It is only handed on if it was measured on THIS build: profiles/r05_pmc_traffic.json carries the hash of the kernel
+    sources it was collected with (the GPU box has no .git, so a commit id could not be checked there); any other source state
+    returns (None, reason).  Returns (bytes or None, provenance dict)."""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, {"reason": "profiles/r05_pmc_traffic.json is missing"}
     if log2_keys != 28 or entropy or shape:
-        return None
+        return None, {"reason": "the committed counters are for 2^28 keys, entropy preset 1, the library's own tile shapes"}
     d = json.load(open(path))
-    src = f"profiles/{name} (builder-run rocprofv3 --pmc passes of the same command; NOT measured by this run)"
-    if vb:
-        d = d.get(f"pairs{vb}")
-        return {"bytes": d["traffic_bytes_per_launch"], "source": src} if d else None
-    m = d.get("tile_keys")
-    if m is not None:
-        return {"bytes": d["traffic_bytes_per_launch"], "source": src} if m == tile_keys else None
-    return {"bytes": d["traffic_bytes_per_launch"], "source": src} if f"<{tile_keys // 32},32,0,0," in d["kernel"] else None
+    now = kernel_sources_sha256()
+    if d.get("kernel_sources_sha256") != now:
+        return None, {"reason": f"the committed counters were collected on kernel sources {d.get('kernel_sources_sha256')}, this tree is {now}: not carried over"}
+    e = d.get("keys" if not vb else f"pairs{vb}", {}).get(kernel)
+    if not e:
+        return None, {"reason": f"no counters committed for value bytes {vb} / {kernel}"}
+    return e["traffic_bytes_per_launch"], {"source": f"profiles/r05_pmc_traffic.json ({d.get('collected_by')}; commit {d.get('commit')}, kernel sources {now}); "
+                                                     "builder-run rocprofv3 --pmc passes of the same command, NOT measured by this run",
+                                           "kernel": e.get("kernel"), "fetch_bytes": e.get("fetch_bytes"), "write_bytes": e.get("write_bytes")}
 
 
 def box_floor(n):
@@ -184,36 +196,68 @@ def box_floor(n):
     }
 
 
-def roofline_block(n, vb, prof, traffic, tile_keys=None, rank_mode=None, floor=None):
+def roofline_block(n, vb, prof, log2_keys, entropy, shape, tile_keys=None, rank_mode=None, floor=None, two_level=False):
     """The dominant kernel (one DigitBinningPass launch) against the HBM peak: algorithmic bytes per launch =
     (4 + 4 key bytes + 2 x value bytes) x n, divided by the launch's average duration from HIP
-    events recorded on the sort's own stream."""
+    events recorded on the sort's own stream.  two_level: the device ran the two-level plan (hybrid_kernels.hpp) — profile slots
+    pass0 / pass1 are its two DigitBinningPasses (top byte; byte 2 on 256 chains), pass2 the bucket-local sort (with the exit of
+    one idle launch), pass3 the exit of another; the sort then MOVES 28 + 6 x value bytes per key, while the metric's algorithmic
+    bytes stay those of the reference's algorithm (36 B/key for uint32 keys), which is how whole_sort.frac_of_8000 is
+    defined — both are in the block."""
     bpk_pass = 8 + 2 * vb
     bpk_sort = 4 + 4 * bpk_pass
-    pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
+    passes = ("pass0", "pass1") if two_level else ("pass0", "pass1", "pass2", "pass3")
+    pass_ms = sum(prof[p] for p in passes) / len(passes)
     achieved = bpk_pass * n / (pass_ms * 1e-3) / 1e9
     whole = bpk_sort * n / (prof["total"] * 1e-3) / 1e9
+    bpk_moved = 4 + 3 * bpk_pass if two_level else bpk_sort
+    traffic, traffic_src = pmc_traffic(log2_keys, vb, entropy, shape, tile_keys, "pass")
+    hist_traffic, hist_src = pmc_traffic(log2_keys, vb, entropy, shape, tile_keys, "histogram")
+
+    def kern(name, ms, bpk, what):
+        gbs = bpk * n / (ms * 1e-3) / 1e9
+        return {"kernel": name, "what": what, "algorithmic_bytes": bpk * n, "ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+
+    if two_level:
+        kernels = [kern("hy_histogram_kernel + hy_reduce_kernel", prof["global_histogram"], 4, "one read of the keys: 16-bit-prefix histogram (+ digit-0 counts)"),
+                   kern("digit_binning_dual_kernel (pass A)", prof["pass0"], bpk_pass, "DigitBinningPass on the top byte, 16 position chains"),
+                   kern("digit_binning_dual_kernel (pass B)", prof["pass1"], bpk_pass, "DigitBinningPass on byte 2 inside the top-byte buckets, 256 chains"),
+                   kern("hy_local_sort_kernel", prof["pass2"], bpk_pass, "one workgroup per 16-bit-prefix bucket: low 16 bits sorted in LDS, in place "
+                        "(LDS-instruction-bound; the slot includes the exit of LSD pass 2's idle launch)")]
+    else:
+        kernels = [kern("global_histogram_kernel + hist_reduce_kernel", prof["global_histogram"], 4, "one read of the keys: four joint histograms")] + \
+                  [kern(f"DigitBinningPass {p}", prof[f"pass{p}"], bpk_pass, "one 8-bit LSD pass") for p in range(4)]
     return {
         "bound": "hbm",
         "kernel": ("digit_binning_dual_kernel (one 8-bit DigitBinningPass per launch; persistent workgroups; plain form for even keys, "
                    "position-chain form when the device plans PF_POS)") if not vb else "digit_binning_kernel (one 8-bit DigitBinningPass)",
+        "plan": ("two-level: histogram of the top 16 bits, DigitBinningPass on byte 3, DigitBinningPass on byte 2 (256 chains), bucket-local LDS sort "
+                 "of the low 16 bits — chosen on the device") if two_level else "GlobalHistogram + Scan + four LSD DigitBinningPasses",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
-        "algorithmic_bytes_per_launch": bpk_pass * n, "avg_launch_ms": pass_ms,
+        "traffic": traffic, "traffic_provenance": traffic_src,
+        "algorithmic_bytes_per_launch": bpk_pass * n, "avg_launch_ms": pass_ms, "launches_averaged": list(passes),
         "frac_of_measured_copy_6290": achieved / 6290.0,
         "whole_sort": {
-            "bytes_per_key": bpk_sort, "ms": prof["total"], "achieved_GBs": whole, "frac_of_8000": whole / HBM_PEAK_GBS,
+            "bytes_per_key": bpk_sort, "bytes_per_key_definition": "the reference algorithm's algorithmic bytes (SURVEY.md 8d: histogram read + 4 x (read + write))",
+            "ms": prof["total"], "achieved_GBs": whole, "frac_of_8000": whole / HBM_PEAK_GBS,
+            "bytes_per_key_moved_by_this_plan": bpk_moved, "moved_GBs": bpk_moved * n / (prof["total"] * 1e-3) / 1e9,
+            "moved_frac_of_8000": bpk_moved * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # BASELINE.json words the target as an "HBM-read roofline": the read half alone (SURVEY.md 8d)
             "read_bytes_per_key": 4 + 4 * (4 + vb),
             "read_only_frac_of_8000": (4 + 4 * (4 + vb)) * n / (prof["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
         "per_kernel_ms": prof,
+        "per_kernel": kernels,
         "tile_keys": tile_keys, "rank_mode": rank_mode,
-        # the kernel furthest below its roofline (4 B/key read): the GlobalHistogram against the same peak
+        # the kernel furthest below its roofline (4 B/key read): the histogram sweep against the same peak
         "global_histogram": {"algorithmic_bytes": 4 * n, "ms": prof["global_histogram"],
                              "achieved_GBs": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9,
-                             "frac": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        **({"frac_of_box_floor": {"pass": floor["tile_copy_ms_steady"] / pass_ms, "whole_sort": floor["floor_ms"] / prof["total"],
+                             "frac": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": hist_traffic, "traffic_provenance": hist_src},
+        **({"frac_of_box_floor": {"pass": floor["tile_copy_ms_steady"] / pass_ms,
+                                  "whole_sort": (floor["read_only_sweep_ms"] + floor["tile_copy_ms_first_after_read"] + 2.0 * floor["tile_copy_ms_steady"]
+                                                 if two_level else floor["floor_ms"]) / prof["total"],
+                                  "whole_sort_floor_definition": "read sweep + 3 tile-shaped copies" if two_level else "read sweep + 4 tile-shaped copies",
                                   "global_histogram": floor["read_only_sweep_ms"] / prof["global_histogram"]}}
            if floor and "floor_ms" in floor and not vb else {}),
     }
@@ -260,8 +304,9 @@ def measure_single(g, n, vb, entropy, steps, warm=1, prof_reps=3):
     sorter.set_profiling(False)
     tile = sorter.partition_size
     rank = sorter.rank_mode
+    two_level = sorter.last_plan()["two_level"]
     sorter.close()
-    return n * steps / dt / 1e9, dt / steps * 1e3, acc, ok, (tile, rank)
+    return n * steps / dt / 1e9, dt / steps * 1e3, acc, ok, (tile, rank, two_level)
 
 
 def more_block(g, n, log2, steps):
@@ -272,28 +317,30 @@ def more_block(g, n, log2, steps):
     ent_bits = (1.0, 0.811, 0.544, 0.337, 0.201)  # OneSweepDispatcher.cuh:201
     out = {"note": "measured after the headline region, same process; steps per entry = %d" % steps}
     for vb, name, cfg in ((4, "pairs_u32", 2), (8, "pairs_u64", 4)):
-        gk, ms, prof, ok, (tile, rk) = measure_single(g, n, vb, 0, steps)
+        gk, ms, prof, ok, (tile, rk, tl) = measure_single(g, n, vb, 0, steps)
         out[name] = {
             "workload": f"2^{log2} (uint32 key, uint{8 * vb} value) pairs OneSweep, 1 MI355X (BASELINE configs[{cfg}])",
             "value": gk, "unit": "GKeys/s", "ms_per_sort": ms, "steps": steps, "tile_keys": tile, "verified_sorted": bool(ok),
             "dtype": f"u32 keys + u{8 * vb} values",
-            "roofline": roofline_block(n, vb, prof, pmc_traffic(log2, vb, 0, "", tile), tile, rk),
+            "roofline": roofline_block(n, vb, prof, log2, 0, "", tile, rk, None, tl),
         }
     rows = {}
     for vb, name in ((0, "keys"), (4, "pairs_u32"), (8, "pairs_u64")):
         row = []
         for preset in range(5):
-            gk, ms, prof, ok, (tile, rk) = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
-            pass_ms = sum(prof[f"pass{p}"] for p in range(4)) / 4.0
+            gk, ms, prof, ok, (tile, rk, tl) = measure_single(g, n, vb, preset, max(2, steps // 2), prof_reps=2)
+            pass_ms = (prof["pass0"] + prof["pass1"]) / 2.0 if tl else sum(prof[f"pass{p}"] for p in range(4)) / 4.0
             row.append({"preset": preset + 1, "entropy_bits": ent_bits[preset], "value": gk, "unit": "GKeys/s", "ms_per_sort": ms,
-                        "verified_sorted": bool(ok), "global_histogram_ms": prof["global_histogram"], "avg_pass_ms": pass_ms,
+                        "verified_sorted": bool(ok), "plan": "two-level" if tl else "LSD passes", "global_histogram_ms": prof["global_histogram"], "avg_pass_ms": pass_ms,
                         "tile_keys": tile, "rank_mode": rk,
                         "global_histogram_frac_of_8000": 4 * n / (prof["global_histogram"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "pass_frac_of_8000": (8 + 2 * vb) * n / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         rows[name] = row
     out["entropy_sweep"] = rows
-    out["entropy_sweep_note"] = ("sorts of skewed keys (presets 2-5; keys-only and pairs) run on position chains in every pass (decided on the "
-                                 "device: the histogram kernel finds the digit groups uneven); counting passes use 12 288-key tiles")
+    out["entropy_sweep_note"] = ("keys-only, preset 1: the two-level plan (decided on the device from the 16-bit-prefix histogram); presets 2-5 (keys-only and "
+                                 "pairs): the four LSD passes on position chains (the histogram kernel finds the prefixes / digit groups uneven); their counting "
+                                 "passes run on 16 384-key tiles with packed counters (keys-only) and on 12 288-key tiles (pairs)")
+    out["other_inputs"] = other_inputs(g, n, max(2, steps // 2))
     # ---- 64-bit keys: eight passes over 8-byte elements, planned by ONE histogram sweep + Scan ----
     n64 = min(n, 1 << 27)
     k64 = [torch.empty(n64, dtype=torch.int64, device="cuda") for _ in range(3)]
@@ -325,12 +372,66 @@ def more_block(g, n, log2, steps):
     return out
 
 
+def other_inputs(g, n, steps):
+    """Inputs the entropy presets do not cover: already sorted, reverse-sorted and block-clustered keys (every 2^20
+    consecutive positions share their top byte) at the headline size, keys-only.  GKeys/s, the plan the device chose, sorted?"""
+    import torch
+    base = torch.empty(n, dtype=torch.int32, device="cuda")
+    alt = torch.empty(n, dtype=torch.int32, device="cuda")
+    work = torch.empty(n, dtype=torch.int32, device="cuda")
+    s = g.OneSweep(n)
+    rows = []
+    for kind in ("sorted", "reverse_sorted", "block_clustered", "uniform"):
+        g.init_random(base, 4242, 0)
+        if kind in ("sorted", "reverse_sorted"):
+            s.sort(base, alt_keys=alt)
+            if kind == "reverse_sorted":
+                base = torch.flip(base, dims=(0,)).contiguous()
+        elif kind == "block_clustered":
+            idx = torch.arange(n, dtype=torch.int32, device="cuda")
+            base = ((base & 0x00FFFFFF) | (((idx >> 20) * 37 & 0xFF) << 24)).contiguous()
+            del idx
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for i in range(steps + 1):
+            work.copy_(base)
+            torch.cuda.synchronize()
+            a.record()
+            s.sort(work, alt_keys=alt)
+            b.record()
+            b.synchronize()
+            if i:
+                tot += a.elapsed_time(b)
+        s.check()
+        ms = tot / steps
+        rows.append({"input": kind, "ms_per_sort": ms, "value": n / ms / 1e6, "unit": "GKeys/s", "plan": "two-level" if s.last_plan()["two_level"] else "LSD passes",
+                     "verified_sorted": bool(g.validate(work) == 0)})
+    s.close()
+    return rows
+
+
+def comparator_block():
+    """ROCm's own device radix sort (rocprim::radix_sort_keys / _pairs) beside this library: sizes 2^16 .. 2^28 and the five entropy presets,
+    keys-only and (u32, u32) pairs, same box, same inputs (tools/rocprim_compare.cpp `sweep`; the reference does the same against CUB,
+    GPUSortingCUDA/Sort/CubDispatcher.cuh:105-404).  Never part of `value`."""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "rocprim_compare")
+    if not os.path.exists(exe):
+        return {"error": "build/rocprim_compare is missing (make tools)"}
+    try:
+        p = subprocess.run([exe, "sweep", "5"], capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+
+
 def size_sweep(g, sorts=10):
     """2^10 .. 2^27 keys, keys-only and (u32, u32) pairs, `sorts` back-to-back sorts of distinct pre-generated inputs per point
     (HIP events around the batch): microseconds per sort and GKeys/s."""
     rows = {"keys": [], "pairs_u32": [], "sorts_per_point": sorts,
             "routes": "n <= 8192: one workgroup, one launch; <= 2^20 (keys-only 2^22, u32 values 2^21): two launches (MSD pass + LDS "
-                      "bucket sorts); above: GlobalHistogram + Scan + 4 DigitBinningPass"}
+                      "bucket sorts); above: GlobalHistogram + Scan + 4 DigitBinningPass; keys-only from 3 x 2^24 keys: the two-level plan"}
     for vb, name in ((0, "keys"), (4, "pairs_u32")):
         for lg in range(10, 28):
             n = 1 << lg
@@ -569,6 +670,7 @@ def main():
     # ---- per-kernel HIP-event profile of the local 4-pass sort (dominant kernel roofline) ----
     prof_sorter = sorter
     prof = None
+    two_level = False
     if rank == 0:
         prof_sorter.set_profiling(True)
         acc = {}
@@ -588,6 +690,7 @@ def main():
                 acc[k_] = acc.get(k_, 0.0) + v_
         prof = {k_: v_ / reps for k_, v_ in acc.items()}
         prof_sorter.set_profiling(False)
+        two_level = prof_sorter.last_plan()["two_level"]
     if dist is not None:
         dist.barrier()
 
@@ -617,13 +720,13 @@ def main():
                          f"OneSweep (BASELINE configs[3] shape, weak scaling)") if not strong else
                         (f"2^{args.log2_keys} uint32 keys in total over {world} GPUs ({n} per GPU): MSD split + RCCL bucket exchange + "
                          f"per-GPU OneSweep (SURVEY 8d cfg 4, strong scaling)"),
-            "timed_region": "whole sort per step: GlobalHistogram (incl. the state clear) + Scan + 4 DigitBinningPass"
+            "timed_region": "whole sort per step: histogram sweep (incl. the state clear) + Scan + every launch of the plan the device chooses "
+                            "(two-level: 2 DigitBinningPass + bucket-local sort; otherwise 4 DigitBinningPass)"
                             + ("" if world == 1 else ", after the top-byte split + bucket exchange of the step (all inside the timed region)"),
             "keys_per_gpu": n, "entropy_preset": args.entropy + 1, "generator": "InitRandom seed 10+i (+1000*rank)",
             "tile_keys": sorter.partition_size, "verified_sorted": bool(sorted_ok and total_ok),
         },
-        "roofline": roofline_block(n, args.pairs, prof, pmc_traffic(args.log2_keys, args.pairs, args.entropy, args.shape, sorter.partition_size),
-                                   sorter.partition_size, sorter.rank_mode, floor),
+        "roofline": roofline_block(n, args.pairs, prof, args.log2_keys, args.entropy, args.shape, sorter.partition_size, sorter.rank_mode, floor, two_level),
     }
     if floor is not None:
         out["box_floor"] = floor
@@ -637,6 +740,7 @@ def main():
         sorter.close()
         torch.cuda.empty_cache()
         out["more"] = more_block(g, n, args.log2_keys, args.more_steps)
+        out["more"]["comparator"] = comparator_block()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_log2)
     else:

@@ -210,28 +210,33 @@ void launch_hy_hist(hipStream_t s, uint32_t grid, const uint32_t* keys, uint32_t
     hipLaunchKernelGGL((gs::hy_histogram_kernel<KT>), dim3(grid), dim3(gs::HY_HIST_THREADS), 0, s, keys, slab, used_words, n, seg_len0, per_wg,
                        wg_per_seg, slices);
 }
-using HyLocalLauncher = void (*)(hipStream_t, uint32_t* keys, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending);
+using HyLocalLauncher = void (*)(hipStream_t, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending, uint32_t lsd_first,
+                                 uint32_t lsd_words);
 template <int KT, int T, int K>
-void launch_hy_local(hipStream_t s, uint32_t* keys, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending) {
-    hipLaunchKernelGGL((gs::hy_local_sort_kernel<KT, T, K>), dim3(gs::HY_BINS), dim3(T), 0, s, keys, tab, slab, n, descending);
+void launch_hy_local(hipStream_t s, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending, uint32_t lsd_first,
+                     uint32_t lsd_words) {
+    hipLaunchKernelGGL((gs::hy_local_sort_kernel<KT, T, K>), dim3(gs::HY_BINS), dim3(T), 0, s, keys, tab, slab, n, descending, lsd_first, lsd_words);
 }
 // the local sort's workgroup by the mean bucket n / 65 536: it holds 1.5 x the mean at the top of its class (uniform keys stay within
 // a few per cent of the mean; what does not fit sends the sort to the LSD passes).  [class][key type]
 struct HyLocalClass { uint32_t max_n, cap; };
-constexpr HyLocalClass g_hy_class[4] = {{1u << 27, 256 * 12}, {1u << 28, 256 * 24}, {1u << 29, 512 * 24}, {GS_MAX_KEYS, 1024 * 24}};
+constexpr HyLocalClass g_hy_class[4] = {{1u << 27, 256 * 12}, {1u << 28, 512 * 12}, {1u << 29, 1024 * 12}, {GS_MAX_KEYS, 1024 * 24}};
 #ifdef GS_MINIMAL
 const HyHistLauncher g_hy_hist[3] = {launch_hy_hist<0>, nullptr, nullptr};
-const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, nullptr, nullptr}, {launch_hy_local<0, 256, 24>, nullptr, nullptr},
-                                          {launch_hy_local<0, 512, 24>, nullptr, nullptr}, {launch_hy_local<0, 1024, 24>, nullptr, nullptr}};
+const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, nullptr, nullptr}, {launch_hy_local<0, 512, 12>, nullptr, nullptr},
+                                          {launch_hy_local<0, 1024, 12>, nullptr, nullptr}, {launch_hy_local<0, 1024, 24>, nullptr, nullptr}};
 #else
 const HyHistLauncher g_hy_hist[3] = {launch_hy_hist<0>, launch_hy_hist<1>, launch_hy_hist<2>};
 const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, launch_hy_local<1, 256, 12>, launch_hy_local<2, 256, 12>},
-                                          {launch_hy_local<0, 256, 24>, launch_hy_local<1, 256, 24>, launch_hy_local<2, 256, 24>},
-                                          {launch_hy_local<0, 512, 24>, launch_hy_local<1, 512, 24>, launch_hy_local<2, 512, 24>},
+                                          {launch_hy_local<0, 512, 12>, launch_hy_local<1, 512, 12>, launch_hy_local<2, 512, 12>},
+                                          {launch_hy_local<0, 1024, 12>, launch_hy_local<1, 1024, 12>, launch_hy_local<2, 1024, 12>},
                                           {launch_hy_local<0, 1024, 24>, launch_hy_local<1, 1024, 24>, launch_hy_local<2, 1024, 24>}};
 #endif
+#ifdef GS_TUNING  // other shapes of the 6144-key class (debug_flags & 7 = 1, 2; u32 keys)
+const HyLocalLauncher g_hy_local_alt[2] = {launch_hy_local<0, 256, 24>, launch_hy_local<0, 1024, 6>};
+#endif
 inline int hy_class(uint32_t n) { return n <= g_hy_class[0].max_n ? 0 : n <= g_hy_class[1].max_n ? 1 : n <= g_hy_class[2].max_n ? 2 : 3; }
-constexpr uint32_t HY_MIN_KEYS_DEFAULT = (1u << 26) + 1u;  // below: buckets of a thousand keys — a workgroup per bucket is mostly launch
+constexpr uint32_t HY_MIN_KEYS_DEFAULT = 3u << 24;  // 50 M keys: measured, the LSD passes win at 2^25 (121 against 102 GKeys/s), the two-level plan at 2^26 (139 against 122): below, its 65 536 buckets are a few hundred keys each and a workgroup per bucket is mostly launch (profiles/r05_two_level_threshold.txt)
 
 }  // namespace
 
@@ -376,7 +381,8 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // (two-level plan: its second pass runs on CHMAX chains)
     const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + (hy ? 2 * gs::CHMAX + 8 : 2 * gs::MAXCH + 2);
     const uint32_t desc_stride = rows * gs::RADIX;
-    const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)np * desc_stride;
+    // (hy: the descriptor regions of LSD passes 2 and 3 are zeroed by the two-level plan's local-sort launch if — and only if — those passes run)
+    const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)(hy ? 2u : np) * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
     // position segments of the first pass: equal, multiples of the histogram chunk — and of the first pass's tile where that is a
     // multiple of the chunk (every shape the library picks): its chains then consist of whole tiles, 16 partial tiles fewer (at
@@ -665,8 +671,13 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                    mode | ((hy && p < 2) ? 128u | 256u : 0u));
                 if (hy && p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
-                    if (!(h->debug_flags & 0x40000000u))  // (bring-up aid, tools/hy_bringup.py: leave pass B's output as it is)
-                        g_hy_local[hy_class(n)][kt](s, k[0], h->hy_tab, h->slab, n, desc_bit);
+                    // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is — the launch still runs, it owns the zeroing of
+                    //  the LSD plan's last two descriptor regions)
+                    HyLocalLauncher local = g_hy_local[hy_class(n)][kt];
+#ifdef GS_TUNING
+                    if (hy_class(n) == 1 && kt == GS_KEY_UINT32 && (h->debug_flags & 7u) >= 1u && (h->debug_flags & 7u) <= 2u) local = g_hy_local_alt[(h->debug_flags & 7u) - 1u];
+#endif
+                    local(s, k[0], h->hy_tab, h->slab, (h->debug_flags & 0x40000000u) ? 0u : n, desc_bit, SLAB_DESC + 2u * plan.desc_stride, 2u * plan.desc_stride);
                 }
             } else
                 (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hy_reduce_kernel(const uint32_t* __restrict__ slices, uint32_t G, uint32_t wg_per_seg,
                                                          uint32_t* __restrict__ tab, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_lo[128], s_hi[128], s_T[NCH];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    __shared__ uint32_t s_acc[RADIX], s_T[NCH];
+    const uint32_t tid = threadIdx.x;
     if (blockIdx.x >= RADIX) {
         const uint32_t x = blockIdx.x - RADIX;
         uint32_t acc = 0;
@@ -242,41 +242,41 @@ __global__ __launch_bounds__(256) void hy_reduce_kernel(const uint32_t* __restri
         hist[hist_index(0, tid, x)] = acc;
         return;
     }
-    const uint32_t b3 = blockIdx.x, w = tid & 127u, par = tid >> 7;  // (par is uniform per wave)
-    if (tid < 128) { s_lo[tid] = 0; s_hi[tid] = 0; }
+    // thread (grp, w4): 16-byte word w4 of the top byte's 128 packed words, in slices grp, grp + 8, ...: U loads in flight
+    const uint32_t b3 = blockIdx.x, w4 = tid & 31u, grp = tid >> 5;
+    s_acc[tid] = 0;
     if (tid < NCH) s_T[tid] = 0;
     __syncthreads();
-    uint32_t lo = 0, hi = 0, cur_x = 0, acc_x = 0;
-    auto flush = [&]() {
-        const uint32_t t = wave_reduce_sum(acc_x);
-        if (lane == 0 && t != 0u) atomicAdd(&s_T[cur_x], t);
-        acc_x = 0;
-    };
-    constexpr uint32_t U = 32;
-    for (uint32_t s0 = par; s0 < G; s0 += 2u * U) {
-        uint32_t v[U];
+    uint32_t a[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, cur_x = 0xffffffffu, acc_x = 0;
+    constexpr uint32_t U = 16;
+    for (uint32_t s0 = grp; s0 < G; s0 += 8u * U) {
+        uint4 v[U];
 #pragma unroll
         for (uint32_t k = 0; k < U; ++k) {
-            const uint32_t s = s0 + 2u * k;
-            v[k] = slices[(size_t)(s < G ? s : G - 1u) * HY_SLICE_WORDS + b3 * 128u + w];  // unconditional on a clamped index, masked below
+            const uint32_t sl = s0 + 8u * k;  // (unconditional on a clamped index, masked below)
+            v[k] = *reinterpret_cast<const uint4*>(slices + (size_t)(sl < G ? sl : G - 1u) * HY_SLICE_WORDS + b3 * 128u + w4 * 4u);
         }
 #pragma unroll
         for (uint32_t k = 0; k < U; ++k) {
-            const uint32_t s = s0 + 2u * k;
-            if (s < G) {  // uniform
-                const uint32_t xs = s / wg_per_seg;
-                if (xs != cur_x) { flush(); cur_x = xs; }
-                lo += v[k] & 0xffffu;
-                hi += v[k] >> 16;
-                acc_x += (v[k] & 0xffffu) + (v[k] >> 16);
+            const uint32_t sl = s0 + 8u * k;
+            if (sl < G) {
+                const uint32_t xs = sl / wg_per_seg;
+                if (xs != cur_x) {
+                    if (acc_x) atomicAdd(&s_T[cur_x], acc_x);
+                    cur_x = xs;
+                    acc_x = 0;
+                }
+                const uint32_t h[8] = {v[k].x & 0xffffu, v[k].x >> 16, v[k].y & 0xffffu, v[k].y >> 16, v[k].z & 0xffffu, v[k].z >> 16, v[k].w & 0xffffu, v[k].w >> 16};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j] += h[j]; acc_x += h[j]; }
             }
         }
     }
-    flush();
-    atomicAdd(&s_lo[w], lo);
-    atomicAdd(&s_hi[w], hi);
+    if (acc_x) atomicAdd(&s_T[cur_x], acc_x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&s_acc[w4 * 8u + j], a[j]);  // word w4 * 4 + j / 2, half j & 1 = prefix (b3, w4 * 8 + j)
     __syncthreads();
-    if (tid < 128) reinterpret_cast<uint2*>(tab + HYT_JOINT)[b3 * 128u + tid] = uint2{s_lo[tid], s_hi[tid]};
+    tab[HYT_JOINT + b3 * RADIX + tid] = s_acc[tid];
     if (tid < NCH) tab[HYT_T + tid * RADIX + b3] = s_T[tid];
 }
 
@@ -288,36 +288,47 @@ __global__ __launch_bounds__(256) void hy_reduce_kernel(const uint32_t* __restri
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t* tab, uint32_t n, uint32_t seg_len0, uint32_t desc_stride,
                                                         uint32_t cap, uint32_t tile) {
-    __shared__ uint32_t s_w[16], s_wmax[16], s_rw[4];
+    // Row i (16 rows) = prefixes [4096 i, 4096 (i + 1)); thread t holds prefixes 4096 i + 4 t .. + 3 of every row: all global
+    // accesses are coalesced 16-byte ones (64 consecutive prefixes per thread, the first form, made every access of a wave touch 64
+    // cache lines: 30 us for 256 KiB).  Wave w of row i = the 256 prefixes of top byte 16 i + w.
+    __shared__ uint32_t s_wt[RADIX];  // [row][wave]: the wave's sum, then the exclusive prefix of that chunk (chunks in prefix order = flat index)
+    __shared__ uint32_t s_wmax[16], s_c4[4], s_rw[4];
     __shared__ uint32_t s_bstart[RADIX + 1], s_rowbase[RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t* hist = slab + SLAB_HIST;
-    uint32_t val[64];
-    uint32_t sum = 0, mx = 0;
+    uint4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = reinterpret_cast<const uint4*>(tab + HYT_JOINT)[i * 1024 + tid];
+    uint32_t incl[16], mx = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint4 v = reinterpret_cast<const uint4*>(tab + HYT_JOINT)[tid * 16u + i];
-        val[4 * i] = v.x; val[4 * i + 1] = v.y; val[4 * i + 2] = v.z; val[4 * i + 3] = v.w;
+        const uint32_t s4 = v[i].x + v[i].y + v[i].z + v[i].w;
+        const uint32_t m01 = v[i].x > v[i].y ? v[i].x : v[i].y, m23 = v[i].z > v[i].w ? v[i].z : v[i].w, m = m01 > m23 ? m01 : m23;
+        mx = m > mx ? m : mx;
+        incl[i] = wave_inclusive_scan_dpp(s4);
+        if (lane == 63) s_wt[i * 16 + wave] = incl[i];
     }
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        sum += val[i];
-        mx = val[i] > mx ? val[i] : mx;
-    }
-    const uint32_t incl = wave_inclusive_scan_dpp(sum);
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)mx, dd, 64);
         mx = o > mx ? o : mx;
     }
-    if (lane == 63) s_w[wave] = incl;
     if (lane == 0) s_wmax[wave] = mx;
     __syncthreads();
-    uint32_t excl = incl - sum, total = 0, maxb = 0;
-    for (uint32_t w = 0; w < 16; ++w) {
-        if (w < wave) excl += s_w[w];
-        total += s_w[w];
-        maxb = s_wmax[w] > maxb ? s_wmax[w] : maxb;
+    uint32_t cv = 0, cincl = 0;
+    if (tid < RADIX) {
+        cv = s_wt[tid];
+        cincl = wave_inclusive_scan_dpp(cv);
+        if (lane == 63) s_c4[wave] = cincl;
+    }
+    __syncthreads();
+    uint32_t total = 0, maxb = 0;
+    for (uint32_t w = 0; w < 4; ++w) total += s_c4[w];
+    for (uint32_t w = 0; w < 16; ++w) maxb = s_wmax[w] > maxb ? s_wmax[w] : maxb;
+    if (tid < RADIX) {
+        uint32_t b = cincl - cv;
+        for (uint32_t w = 0; w < wave; ++w) b += s_c4[w];
+        s_wt[tid] = b;
     }
     const bool valid = hist[HIST_TABLE_WORDS + HX_HY_BAD] == 0u && maxb <= cap && total == n;  // uniform
     if (tid == 0) slab[SLAB_HY + HY_MAXBUCKET] = maxb;
@@ -326,22 +337,24 @@ __global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t*
         if (tid == 0) hist[HIST_TABLE_WORDS + HX_SKEW] = 1u;
         return;
     }
-    // bucket starts (exclusive prefix over the 16-bit prefixes); val[] becomes the prefix
-    {
-        uint32_t run = excl;
+    __syncthreads();
+    // (thread d < 256: keys of position segment x whose top byte is d, for pass A's seed rows — requested here, used at the end)
+    uint32_t tseg[NCH];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const uint32_t c = val[i];
-            val[i] = run;
-            run += c;
-        }
+    for (uint32_t x = 0; x < NCH; ++x) tseg[x] = tid < RADIX ? tab[HYT_T + x * RADIX + tid] : 0u;
+    // bucket starts (exclusive prefix over the 16-bit prefixes); v[] becomes the prefix
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            reinterpret_cast<uint4*>(tab + HYT_BASE)[tid * 16u + i] = uint4{val[4 * i], val[4 * i + 1], val[4 * i + 2], val[4 * i + 3]};
-        if (tid == 1023) tab[HYT_BASE + HY_BINS] = run;  // == n
+    for (int i = 0; i < 16; ++i) {
+        const uint4 c = v[i];
+        const uint32_t e = s_wt[i * 16 + wave] + incl[i] - (c.x + c.y + c.z + c.w);
+        v[i] = uint4{e, e + c.x, e + c.x + c.y, e + c.x + c.y + c.z};
+        reinterpret_cast<uint4*>(tab + HYT_BASE)[i * 1024 + tid] = v[i];
+        if (lane == 0) s_bstart[i * 16 + wave] = e;  // start of top byte 16 i + wave
     }
-    if ((tid & 3u) == 0u) s_bstart[tid >> 2] = excl;
-    if (tid == 0) s_bstart[RADIX] = n;
+    if (tid == 0) {
+        s_bstart[RADIX] = n;
+        tab[HYT_BASE + HY_BINS] = n;
+    }
     __syncthreads();
     uint32_t* info0 = slab + SLAB_INFO;
     uint32_t* info1 = info0 + INFO_STRIDE;
@@ -364,22 +377,21 @@ __global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t*
         info1[I_ROW + tid] = rb;
     }
     __syncthreads();
-    {   // seed rows of pass B: digit d of chain c starts at the start of prefix (c, d)
-        const uint32_t c = tid >> 2, dq = (tid & 3u) * 64u;
-        uint4* row = reinterpret_cast<uint4*>(desc1 + (size_t)s_rowbase[c] * RADIX + dq);
+    // seed rows of pass B: digit d of chain c starts at the start of prefix (c, d); a wave writes the row of chain 16 i + wave
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            row[i] = uint4{(val[4 * i] << 2) | FLAG_INCLUSIVE, (val[4 * i + 1] << 2) | FLAG_INCLUSIVE, (val[4 * i + 2] << 2) | FLAG_INCLUSIVE,
-                           (val[4 * i + 3] << 2) | FLAG_INCLUSIVE};
+    for (int i = 0; i < 16; ++i) {
+        uint4* row = reinterpret_cast<uint4*>(desc1 + (size_t)s_rowbase[i * 16 + wave] * RADIX);
+        row[lane] = uint4{(v[i].x << 2) | FLAG_INCLUSIVE, (v[i].y << 2) | FLAG_INCLUSIVE, (v[i].z << 2) | FLAG_INCLUSIVE, (v[i].w << 2) | FLAG_INCLUSIVE};
     }
     // ---- pass A: the top byte over NCH position segments of the unsorted input (as the first pass of any sort)
     if (tid < RADIX) {
         uint32_t run = s_bstart[tid], rowa = 0;
+#pragma unroll
         for (uint32_t x = 0; x < NCH; ++x) {
             const unsigned long long a = (unsigned long long)x * seg_len0, b = a + seg_len0;
             const uint32_t s0 = a < n ? (uint32_t)a : n, s1 = b < n ? (uint32_t)b : n;
             desc0[(size_t)rowa * RADIX + tid] = (run << 2) | FLAG_INCLUSIVE;
-            run += tab[HYT_T + x * RADIX + tid];
+            run += tseg[x];
             if (tid == 0) {
                 info0[I_START + x] = s0;
                 info0[I_END + x] = s1;
@@ -415,22 +427,32 @@ static_assert(CHMAX == RADIX, "pass B: one chain per top-byte value");
 // are indistinguishable, the reverse of the stable ascending order is any descending order).
 // ---------------------------------------------------------------------------
 template <int KT, int THREADS_, int KPT_>
-__global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slab,
-                                                                 uint32_t n, uint32_t descending) {
+__global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys, const uint32_t* __restrict__ tab, uint32_t* __restrict__ slab,
+                                                                 uint32_t n, uint32_t descending, uint32_t lsd_desc_first /*slab word*/,
+                                                                 uint32_t lsd_desc_words) {
     constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
     constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
-    static_assert(THREADS >= RADIX && KPT % 2 == 0, "one digit per thread in the scans; ranks are packed two per register");
+    static_assert(THREADS >= RADIX && KPT % 2 == 0 && WAVES % 2 == 0 && TILE < 65536, "one digit per thread in the scans; ranks and counters are packed two per word");
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[TILE];
-    __shared__ uint32_t s_whist[WAVES * RADIX];
+    __shared__ uint32_t s_cnt[WAVES / 2 * RADIX];  // pass 1: [0 .. 255] one table for the workgroup; pass 2: per-wave counters, waves 2k and 2k + 1 in one word
     __shared__ uint32_t s_wtot[4];
-    if (__builtin_amdgcn_readfirstlane((int)slab[SLAB_HY + HY_VALID]) == 0) return;  // the sort runs on the LSD passes
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t start = tab[HYT_BASE + blockIdx.x], count = tab[HYT_BASE + blockIdx.x + 1u] - start;
+    // (all three words requested together: one scalar round trip in front of the key loads, not two)
+    const uint32_t valid = slab[SLAB_HY + HY_VALID], b_lo = tab[HYT_BASE + blockIdx.x], b_hi = tab[HYT_BASE + blockIdx.x + 1u];
+    if (__builtin_amdgcn_readfirstlane((int)valid) == 0) {
+        // The sort runs on the LSD passes.  This launch sits between their second and third pass: it zeroes the descriptor regions
+        // of passes 2 and 3, which the histogram kernel therefore does not have to (the two-level plan never touches them:
+        // 2 x 17 MiB of stores per sort at 2^28 keys).
+        uint4* z = reinterpret_cast<uint4*>(slab + lsd_desc_first);
+        const uint32_t nz = lsd_desc_words / 4u;
+        for (uint32_t i = blockIdx.x * THREADS_ + tid; i < nz; i += gridDim.x * THREADS_) z[i] = uint4{0u, 0u, 0u, 0u};
+        return;
+    }
+    const uint32_t start = b_lo, count = b_hi - b_lo;
     if (count == 0u || count > TILE || start > n || count > n - start) return;  // (the last three cannot happen with a valid plan)
     const uint32_t at = descending ? n - start - count : start;
     const uint32_t kpt = (uint32_t)__builtin_amdgcn_readfirstlane((int)((count + THREADS - 1u) / THREADS));  // uniform, 1 .. KPT
     const uint32_t my_base = wave * (64u * kpt) + lane;
-    uint32_t* whist = s_whist + wave * RADIX;
     uint32_t key[KPT];
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
@@ -438,53 +460,97 @@ __global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys,
         const uint32_t slot = my_base + i * 64u;
         key[i] = keys[at + (slot < count ? slot : count - 1u)];
     }
+    if (tid < RADIX) s_cnt[tid] = 0;
 #pragma unroll
     for (int i = 0; i < KPT; ++i)
-        if ((uint32_t)i < kpt) key[i] = my_base + i * 64u < count ? to_bits<KT>(key[i]) : 0xffffffffu;
-#pragma unroll 1
-    for (uint32_t shift = 0; shift < 16; shift += 8) {
-        for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) s_whist[i] = 0;
-        __syncthreads();
-        uint32_t off[KPT / 2];
-        mid_rank<1, KPT>(key, shift, my_base, count, whist, off, kpt);
-        __syncthreads();
-        uint32_t run = 0, scan_incl = 0;
-        if (tid < RADIX) {
+        if ((uint32_t)i < kpt) key[i] = to_bits<KT>(key[i]);
+    __syncthreads();
+    // The kernel is bound by its LDS instructions (two passes x rank / base / stage / read back, profiles/r05_*): whatever is not
+    // per key is kept small.
+    // ---- pass 1, byte 0: NOT stable — the keys carry nothing along, so any order among equal low bytes will do — which lets the
+    // whole workgroup rank on ONE counter table (arrival order) instead of one per wave
+    uint32_t off[KPT / 2];
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const uint32_t c = s_whist[w * RADIX + tid];
-                s_whist[w * RADIX + tid] = run;
-                run += c;
-            }
-            scan_incl = wave_inclusive_scan_dpp(run);
-            if (lane == 63) s_wtot[wave] = scan_incl;
-        }
-        __syncthreads();
-        if (tid < RADIX) {
-            uint32_t wbase = 0;
-            for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
-            const uint32_t dpre = wbase + scan_incl - run;
+    for (int i = 0; i < KPT / 2; ++i) off[i] = 0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) s_whist[w * RADIX + tid] += dpre;
-        }
-        __syncthreads();
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        if (my_base + i * 64u < count)
+            off[i >> 1] |= __hip_atomic_fetch_add(&s_cnt[key[i] & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << (16 * (i & 1));
+    }
+    __syncthreads();
+    uint32_t c = 0, scan_incl = 0;
+    if (tid < RADIX) {
+        c = s_cnt[tid];
+        scan_incl = wave_inclusive_scan_dpp(c);
+        if (lane == 63) s_wtot[wave] = scan_incl;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
+        s_cnt[tid] = wbase + scan_incl - c;  // start of the digit's run
+    }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            if ((uint32_t)i >= kpt) continue;
-            const uint32_t lpos = ((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_whist[wave * RADIX + ((key[i] >> shift) & 255u)];
-            if (my_base + i * 64u < count) s_stage[lpos] = key[i];
-        }
-        __syncthreads();
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        if (my_base + i * 64u < count) s_stage[((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + s_cnt[key[i] & 255u]] = key[i];
+    }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            if ((uint32_t)i >= kpt) continue;
-            key[i] = s_stage[my_base + i * 64u];
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        key[i] = s_stage[my_base + i * 64u];  // (slots >= count hold nothing: masked wherever they are used)
+    }
+    // ---- pass 2, byte 1: stable (it must keep pass 1's order).  Per-wave counters, two waves per word (a wave counts at most
+    // 64 x KPT, a stage slot is < TILE < 65 536: a half never carries into its neighbour)
+    for (uint32_t i = tid; i < WAVES / 2 * RADIX; i += THREADS) s_cnt[i] = 0;  // (pass 1's readers of s_cnt are behind the barrier above)
+    __syncthreads();
+    const uint32_t wsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((wave & 1u) * 16u));
+    uint32_t* wh = s_cnt + (wave >> 1) * RADIX;
+#pragma unroll
+    for (int i = 0; i < KPT / 2; ++i) off[i] = 0;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        if (my_base + i * 64u < count) {
+            const uint32_t r = __hip_atomic_fetch_add(&wh[(key[i] >> 8) & 255u], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            off[i >> 1] |= ((r >> wsh) & 0xffffu) << (16 * (i & 1));
         }
     }
+    __syncthreads();
+    uint32_t run = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int p = 0; p < WAVES / 2; ++p) {
+            const uint32_t c2 = s_cnt[p * RADIX + tid];
+            s_cnt[p * RADIX + tid] = run | ((run + (c2 & 0xffffu)) << 16);
+            run += (c2 & 0xffffu) + (c2 >> 16);
+        }
+        scan_incl = wave_inclusive_scan_dpp(run);
+        if (lane == 63) s_wtot[wave] = scan_incl;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
+        const uint32_t dpre = wbase + scan_incl - run;
+#pragma unroll
+        for (int p = 0; p < WAVES / 2; ++p) s_cnt[p * RADIX + tid] += dpre * 0x10001u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        if (my_base + i * 64u < count)
+            s_stage[((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + ((wh[(key[i] >> 8) & 255u] >> wsh) & 0xffffu)] = key[i];
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t slot = my_base + i * 64u;
-        if ((uint32_t)i < kpt && slot < count) keys[at + (descending ? count - 1u - slot : slot)] = from_bits<KT>(key[i]);
+        if ((uint32_t)i < kpt && slot < count) keys[at + (descending ? count - 1u - slot : slot)] = from_bits<KT>(s_stage[slot]);
     }
 }
 

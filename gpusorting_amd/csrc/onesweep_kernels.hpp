@@ -989,8 +989,14 @@ __device__ __forceinline__ void binning_body(
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
     if (mode & 128u) shift_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_SHIFT]);
-    // chain a workgroup asks first: blockIdx modulo the pass's chain count
-    const uint32_t chmask = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) - 1u : NCH - 1u;
+    // Chain a workgroup asks first: blockIdx modulo NCH, in chain GROUP `group`.  The LSD plans have one group (NCH chains).  A pass on
+    // CHMAX chains (the two-level plan's second pass: one chain per top-byte bucket) is walked group by group — NCH chains at a time,
+    // each by the 1 / NCH of the workgroups that share its lane, moving on to chain + NCH when it is fully claimed — so that at any
+    // time ~NCH chains are live with 32 workgroups each, exactly the LSD passes' picture: every (chain, digit) write cursor is fed by
+    // a whole row of neighbouring tiles (with all 256 chains live at once, two workgroups each, the pass wrote through 65 536 cursors
+    // with two tiles behind each and ran at 0.66 ms instead of 0.47: DRAM pages served 512 bytes per activation, profiles/r05_*).
+    const uint32_t ngroups = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) / NCH : 1u;
+    uint32_t group = 0;  // uniform; persistent workgroups keep it across their tiles
     static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || VB == 4 || (VB == 8 && VR == 2))),
                   "the position-chain forms exist for 32-bit keys, keys-only, with 4-byte values (staged behind the keys) or with 8-byte values (two staging rounds), LDS-atomic ranking");
     using V = typename ValT<VB>::type;
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ void binning_body(
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
     // a chain is the start order, so every predecessor of a claimed tile is running.
     // Only when that chain is already fully claimed does thread 0 try the others. ----
-    uint32_t chain = blockIdx.x & chmask;
+    uint32_t chain = (blockIdx.x & (NCH - 1)) + group * NCH;
     // geometry of the fast-path chain: requested before the ticket is (scalar loads that depend on blockIdx only), so
     // their round trip runs beside the ticket atomic's instead of after the barrier
     const uint32_t seg_start_f = info[I_START + chain], seg_end_f = info[I_END + chain], row_f = info[I_ROW + chain];
@@ -1150,6 +1156,12 @@ __device__ __forceinline__ void binning_body(
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
     uint32_t seg_start = uni(seg_start_f), seg_end = uni(seg_end_f), row0 = uni(row_f);
     if (GS_UNLIKELY(tile >= chain_tiles(seg_start, seg_end, TILE))) {  // uniform
+        if constexpr (PERSIST) {
+            if (group + 1u < ngroups) {  // this lane's chain of the group is fully claimed: on to the next group's
+                ++group;
+                continue;
+            }
+        }
         // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
         // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
         __syncthreads();

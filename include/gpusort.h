@@ -184,7 +184,7 @@ gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
  * 16 bits in LDS, in place: 28 bytes per key, the same result bit for bit.  It needs buckets that fit a workgroup (near-uniform top
  * 16 bits); whether they do is decided ON THE DEVICE from the histogram (no host round trip): otherwise the same launches run the
  * four LSD passes on position chains.
- *   0 (default): the two-level plan is offered from 2^26 + 1 keys up;  1: never (the LSD passes only);  2 (tests): offered at every
+ *   0 (default): the two-level plan is offered from 3 x 2^24 (50 M) keys up;  1: never (the LSD passes only);  2 (tests): offered at every
  *   size from gs_onesweep_options::position_chains_min_log2 up.  GS_ERR_MODE for 2 on a handle without the plan's tables (pairs,
  *   max_keys <= 2^20, or created with plan 1).
  * gs_onesweep_last_plan (synchronous) reports what the device decided for the last sort: *plan = 1 the two-level plan ran, 0 the LSD

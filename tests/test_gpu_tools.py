@@ -76,3 +76,19 @@ def test_torch_free_multi_gpu_harness_on_one_gpu(tools, mode, pairs):
     assert d["value"] > 1.0 and d["phase_ms_max_over_ranks"]["local_sort"] > 0.0, d
     assert 0.0 < d["local_sort_rank0"]["roofline"]["frac"] < 1.0, d
     assert d["rank_exit_codes"] == [0], d
+
+
+@pytest.mark.parametrize("pairs", [0, 4])
+def test_world_8_rehearsal_on_one_gpu(tools, pairs):
+    """the sharded pipeline end to end at the world size BASELINE.json configs[3] names, on a one-GPU box:
+    `mgpu_main --ranks 8 --share-gpu` runs eight rank threads on device 0 over an in-process transport (a barrier and device-to-device
+    copies per collective; RCCL refuses several ranks on one device) — the 8-way plan, 7 peers per rank, 8-entry count and
+    displacement tables, the closing status gather, the local sorts.  The line must verify: every bucket sorted, sizes add up to
+    8 x 2^22, bucket borders ascend across the ranks."""
+    import json
+    rc, out = _run([os.path.join(tools, "mgpu_main"), "--ranks", "8", "--share-gpu", "--log2", "22", "--iters", "2", "--pairs", str(pairs)])
+    assert rc == 0, out[-2000:]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["verified"] is True and d["n_gpus"] == 8 and d["value_bytes"] == pairs, d
+    assert d["rank_exit_codes"] == [0] * 8 and d["links_used_per_rank"] == 7, d
+    assert d["bytes_sent_off_rank"]["sum"] > 0.8 * 7 / 8 * 8 * (1 << 22) * (4 + pairs), d   # ~7/8 of every shard leaves its rank
