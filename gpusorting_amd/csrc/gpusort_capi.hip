@@ -203,19 +203,17 @@ inline size_t ls_table_words(uint32_t max_keys) { const size_t p = ls_nt_pad_for
 
 // ---- two-level plan (hybrid_kernels.hpp) ----
 using HyHistLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n, uint32_t seg_len0,
-                                uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices);
+                                uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices, uint32_t cap);
 template <int KT>
 void launch_hy_hist(hipStream_t s, uint32_t grid, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n, uint32_t seg_len0,
-                    uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices) {
+                    uint32_t per_wg, uint32_t wg_per_seg, uint32_t* slices, uint32_t cap) {
     hipLaunchKernelGGL((gs::hy_histogram_kernel<KT>), dim3(grid), dim3(gs::HY_HIST_THREADS), 0, s, keys, slab, used_words, n, seg_len0, per_wg,
-                       wg_per_seg, slices);
+                       wg_per_seg, slices, cap);
 }
-using HyLocalLauncher = void (*)(hipStream_t, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending, uint32_t lsd_first,
-                                 uint32_t lsd_words);
+using HyLocalLauncher = void (*)(hipStream_t, uint32_t grid, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending);
 template <int KT, int T, int K>
-void launch_hy_local(hipStream_t s, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending, uint32_t lsd_first,
-                     uint32_t lsd_words) {
-    hipLaunchKernelGGL((gs::hy_local_sort_kernel<KT, T, K>), dim3(gs::HY_BINS), dim3(T), 0, s, keys, tab, slab, n, descending, lsd_first, lsd_words);
+void launch_hy_local(hipStream_t s, uint32_t grid, uint32_t* keys, const uint32_t* tab, uint32_t* slab, uint32_t n, uint32_t descending) {
+    hipLaunchKernelGGL((gs::hy_local_sort_kernel<KT, T, K>), dim3(grid), dim3(T), 0, s, keys, tab, slab, n, descending);
 }
 // the local sort's workgroup by the mean bucket n / 65 536: it holds 1.5 x the mean at the top of its class (uniform keys stay within
 // a few per cent of the mean; what does not fit sends the sort to the LSD passes).  [class][key type]
@@ -381,7 +379,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // (two-level plan: its second pass runs on CHMAX chains)
     const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + (hy ? 2 * gs::CHMAX + 8 : 2 * gs::MAXCH + 2);
     const uint32_t desc_stride = rows * gs::RADIX;
-    // (hy: the descriptor regions of LSD passes 2 and 3 are zeroed by the two-level plan's local-sort launch if — and only if — those passes run)
+    // (hy: the descriptor regions of LSD passes 2 and 3 are zeroed by the launch of LSD pass 1 (mode bit 9) if — and only if — those passes run)
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)(hy ? 2u : np) * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
     // position segments of the first pass: equal, multiples of the histogram chunk — and of the first pass's tile where that is a
@@ -406,7 +404,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
         const uint32_t wg_per_seg = seg_tiles < h->hy_grid / gs::NCH ? (seg_tiles ? seg_tiles : 1u) : h->hy_grid / gs::NCH;
         const uint32_t G = wg_per_seg * gs::NCH;
         const uint32_t per_wg = div_up(div_up(seg_len0, wg_per_seg), gs::HIST_CHUNK) * gs::HIST_CHUNK;
-        g_hy_hist[kt](s, G, static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, per_wg, wg_per_seg, h->partials);
+        g_hy_hist[kt](s, G, static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, per_wg, wg_per_seg, h->partials, g_hy_class[hy_class(n)].cap);
         hipLaunchKernelGGL(gs::hy_reduce_kernel, dim3(gs::RADIX + gs::NCH), dim3(256), 0, s, h->partials, G, wg_per_seg, h->hy_tab, h->slab + SLAB_HIST);
         if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
         hipLaunchKernelGGL(gs::hy_scan_kernel, dim3(1), dim3(1024), 0, s, h->slab, h->hy_tab, n, seg_len0, desc_stride, g_hy_class[hy_class(n)].cap, tile);
@@ -668,16 +666,15 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                 g_dual[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
-                                   mode | ((hy && p < 2) ? 128u | 256u : 0u));
+                                   mode | ((hy && p < 2) ? 128u | 256u : 0u) | ((hy && p == 1) ? 512u : 0u));
                 if (hy && p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
-                    // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is — the launch still runs, it owns the zeroing of
-                    //  the LSD plan's last two descriptor regions)
                     HyLocalLauncher local = g_hy_local[hy_class(n)][kt];
 #ifdef GS_TUNING
                     if (hy_class(n) == 1 && kt == GS_KEY_UINT32 && (h->debug_flags & 7u) >= 1u && (h->debug_flags & 7u) <= 2u) local = g_hy_local_alt[(h->debug_flags & 7u) - 1u];
 #endif
-                    local(s, k[0], h->hy_tab, h->slab, (h->debug_flags & 0x40000000u) ? 0u : n, desc_bit, SLAB_DESC + 2u * plan.desc_stride, 2u * plan.desc_stride);
+                    // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is)
+                    if (!(h->debug_flags & 0x40000000u)) local(s, gs::HY_BINS, k[0], h->hy_tab, h->slab, n, desc_bit);
                 }
             } else
                 (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,

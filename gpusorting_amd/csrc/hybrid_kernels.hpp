@@ -62,7 +62,7 @@ constexpr uint32_t HY_FOLD_CHUNKS = 256;  // the digit-0 replicas are folded at 
 template <int KT>
 __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_histogram_kernel(
     const uint32_t* __restrict__ keys, uint32_t* slab, size_t slab_used_words, uint32_t n, uint32_t seg_len0, uint32_t per_wg,
-    uint32_t wg_per_seg, uint32_t* slices) {
+    uint32_t wg_per_seg, uint32_t* slices, uint32_t cap /*keys the bucket-local sort's workgroup holds*/) {
     static_assert(KeyWords<KT>::value == 1, "32-bit keys");
     constexpr uint32_t T = HY_HIST_THREADS;
     __shared__ __attribute__((aligned(16))) uint32_t s_j[HY_JOINT_WORDS];
@@ -117,6 +117,11 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
     bool skew = false;               // wave-uniform: a dominant prefix was seen; cleared when it fades
     uint32_t sticky = 0xffffffffu;   // wave-uniform guess of it
     uint32_t since_fold = 0;
+    // joint_off (workgroup-uniform, re-read once per work item): THIS workgroup alone has counted more than `cap` keys under one
+    // prefix — that bucket cannot be sorted by one workgroup, the plan is void whatever the other workgroups see (an exact
+    // verdict, not a sample: those keys exist).  It says so (HX_HY_BAD) and stops counting prefixes: skewed keys (presets 3-5 of the
+    // entropy sweep: 12 % .. 60 % under prefix 0) then cost this kernel one add per key, like the LSD plan's histogram kernel.
+    bool joint_off = false;
     typedef uint32_t hv4 __attribute__((ext_vector_type(4)));
     auto ld16 = [](const uint32_t* q) -> uint4 {
         const hv4 v = __builtin_nontemporal_load(reinterpret_cast<const hv4*>(q));
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
             const uint32_t d = b[j] & 255u;
             atomicAdd(&s_r[(d >> 1) * 32u + (lane & 31u)], 1u << ((d & 1u) * 16u));
         }
+        if (joint_off) return;  // uniform
         if (probe) {
             const uint32_t p0 = b[0] >> 16;
             const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
@@ -154,6 +160,15 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
         }
         const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b[0] >> 16));
         const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((b[0] >> 16) == f));
+        // Relearn BEFORE the adds: on sorted input every chunk of 4096 keys lies under a new prefix — relearning behind the adds put
+        // each chunk's 64 lanes x 4 keys on ONE counter individually first (0.71 ms for the sweep on sorted keys, profiles/
+        // r05_sorted_inputs.txt).
+        if (pc >= 24 && f != sticky) sticky = f;
+        // every lane's four keys under the remembered prefix (sorted / constant input): one add of 256 and done
+        if (__builtin_amdgcn_ballot_w64((b[0] >> 16) == sticky && (b[1] >> 16) == sticky && (b[2] >> 16) == sticky && (b[3] >> 16) == sticky) == ~0ull) {
+            if (lane == 0) add_joint(sticky, 256u);
+            return;
+        }
         uint32_t hit = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -176,6 +191,14 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
             uint4 t[UNROLL];
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; ++u) t[u] = ld16(keys + c0 + u * HIST_CHUNK + tid * 4u);
+            if (!joint_off) {
+                // the wave's dominant prefix against the bucket limit (one LDS read per wave and work item; a 16-bit counter is
+                // read long before it could wrap: cap < 2^15)
+                const uint32_t pf = to_bits<KT>((uint32_t)__builtin_amdgcn_readfirstlane((int)t[0].x)) >> 16;  // the prefix of the wave's first key: a hot prefix is drawn often
+                if (lane == 0 && (((s_j[pf >> 1] >> ((pf & 1u) << 4)) & 0xffffu) > cap ||
+                                  (skew && ((s_j[sticky >> 1] >> ((sticky & 1u) << 4)) & 0xffffu) > cap))) s_red[3] = 1u;
+                joint_off = __builtin_amdgcn_readfirstlane((int)s_red[3]) != 0;  // (a benign race: a wave that misses the flag this time sees it next time)
+            }
 #pragma unroll
             for (uint32_t u = 0; u < UNROLL; ++u)
                 process(uint4{to_bits<KT>(t[u].x), to_bits<KT>(t[u].y), to_bits<KT>(t[u].z), to_bits<KT>(t[u].w)}, u == 0);
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
     }
     __syncthreads();
     if (tid == 0) {
-        if (s_red[0] != end - begin) atomicOr(&hist[HIST_TABLE_WORDS + HX_HY_BAD], 1u);
+        if (s_red[0] != end - begin || s_red[3] != 0u) atomicOr(&hist[HIST_TABLE_WORDS + HX_HY_BAD], 1u);
         // the OR / AND of all keys: how a sort planned on position chains finds its constant bytes (one atomic pair per workgroup)
         atomicOr(&hist[HIST_TABLE_WORDS + HX_OR], s_red[1]);
         atomicOr(&hist[HIST_TABLE_WORDS + HX_NAND], s_red[2]);
@@ -428,8 +451,7 @@ static_assert(CHMAX == RADIX, "pass B: one chain per top-byte value");
 // ---------------------------------------------------------------------------
 template <int KT, int THREADS_, int KPT_>
 __global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys, const uint32_t* __restrict__ tab, uint32_t* __restrict__ slab,
-                                                                 uint32_t n, uint32_t descending, uint32_t lsd_desc_first /*slab word*/,
-                                                                 uint32_t lsd_desc_words) {
+                                                                 uint32_t n, uint32_t descending) {
     constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
     constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
     static_assert(THREADS >= RADIX && KPT % 2 == 0 && WAVES % 2 == 0 && TILE < 65536, "one digit per thread in the scans; ranks and counters are packed two per word");
@@ -437,17 +459,12 @@ __global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys,
     __shared__ uint32_t s_cnt[WAVES / 2 * RADIX];  // pass 1: [0 .. 255] one table for the workgroup; pass 2: per-wave counters, waves 2k and 2k + 1 in one word
     __shared__ uint32_t s_wtot[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // (all three words requested together: one scalar round trip in front of the key loads, not two)
+    // (the plan's valid word and the bucket's geometry are requested together: one scalar round trip in front of the key loads.
+    //  Measured and not kept: fewer workgroups that loop over 2 / 4 / 8 buckets each, the next bucket's geometry requested ahead —
+    //  0.544 ms against 0.482 for one workgroup per bucket, profiles/r05_local_sort_variants.txt: the kernel lives on many
+    //  independent workgroups per CU; the price is 65 536 workgroups that exit at once when the sort runs on the LSD passes, 0.03 ms.)
     const uint32_t valid = slab[SLAB_HY + HY_VALID], b_lo = tab[HYT_BASE + blockIdx.x], b_hi = tab[HYT_BASE + blockIdx.x + 1u];
-    if (__builtin_amdgcn_readfirstlane((int)valid) == 0) {
-        // The sort runs on the LSD passes.  This launch sits between their second and third pass: it zeroes the descriptor regions
-        // of passes 2 and 3, which the histogram kernel therefore does not have to (the two-level plan never touches them:
-        // 2 x 17 MiB of stores per sort at 2^28 keys).
-        uint4* z = reinterpret_cast<uint4*>(slab + lsd_desc_first);
-        const uint32_t nz = lsd_desc_words / 4u;
-        for (uint32_t i = blockIdx.x * THREADS_ + tid; i < nz; i += gridDim.x * THREADS_) z[i] = uint4{0u, 0u, 0u, 0u};
-        return;
-    }
+    if (__builtin_amdgcn_readfirstlane((int)valid) == 0) return;  // the sort runs on the LSD passes
     const uint32_t start = b_lo, count = b_hi - b_lo;
     if (count == 0u || count > TILE || start > n || count > n - start) return;  // (the last three cannot happen with a valid plan)
     const uint32_t at = descending ? n - start - count : start;

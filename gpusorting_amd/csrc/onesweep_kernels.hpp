@@ -129,6 +129,7 @@ constexpr uint32_t I_NCH = PASS_FLAGS + 1;     // chains in use (NCH, or CHMAX: 
 constexpr uint32_t I_NEXT_SHIFT = PASS_FLAGS + 2;  // PF_POS: bit position of the digit of the next pass that runs (this pass counts it per
                                                    // output position segment while it scatters), ~0 = nothing to count
 constexpr uint32_t I_SEGLOG = PASS_FLAGS + 3;      // PF_POS: log2 of the position segments of the passes behind the first one
+constexpr uint32_t I_DSTRIDE = PASS_FLAGS + 5;     // words of one pass's descriptor region (launches with mode bit 9 zero the two regions behind their own)
 constexpr uint32_t I_SHIFT = PASS_FLAGS + 4;       // bit position of this pass's digit (launches with mode bit 7 take it from here: the plan is the device's)
 constexpr uint32_t I_MODE = PASS_FLAGS + 6;        // PF_SKEW passes: the most frequent value of this pass's digit
 constexpr uint32_t INFO_STRIDE = ((PASS_FLAGS + 7 + 31) / 32) * 32;
@@ -533,6 +534,9 @@ __global__ __launch_bounds__(GHIST_THREADS, GS_GHIST_WAVES_PER_SIMD) void global
                         //  conflicts among the OTHER hot bins, profiles/r02_skew_rank_fixed_mode.txt)
                         const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin[0]);
                         const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bin[0] == b0));
+                        // (round 5: relearn BEFORE the adds — on sorted input every chunk lies under a new dominant bin, and relearning
+                        //  behind the adds put 64 lanes x 4 keys on one counter one by one first: 0.88 ms for this kernel on sorted keys)
+                        if (pc >= 24 && b0 != sticky[q]) sticky[q] = b0;
                         uint32_t hit = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -894,6 +898,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const uint32_t* hist, uint32_
         my_info[I_NEXT_SHIFT] = (pos && later) ? 8u * (uint32_t)__builtin_ctz(later) : 0xffffffffu;
         my_info[I_SEGLOG] = seglog;
         my_info[I_SHIFT] = 8u * q;
+        my_info[I_DSTRIDE] = desc_stride;
         my_info[I_MODE] = s_mode ? 255u - (uint32_t)(s_mode & 255u) : 0xffffffffu;
     }
     if (!counted) return;  // PF_POS behind the first pass: the pass's own workgroups derive skew flag, mode digit and seeds
@@ -985,7 +990,7 @@ __device__ __forceinline__ void binning_body(
                     pass is also launched in its position-chain form — this launch works only if the plan's PF_POS matches its POS
                     (checked first); bit7: the digit's bit position comes from the info block (I_SHIFT), not from shift_full; bit8: the
                     chain count comes from the info block BEFORE the first ticket (I_NCH may be CHMAX: the two-level plan's second pass) —
-                    sorts whose plan (LSD passes or the two-level plan) the Scan kernels choose on the device*/) {
+                    sorts whose plan (LSD passes or the two-level plan) the Scan kernels choose on the device; bit9: see below*/) {
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
     if (mode & 128u) shift_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_SHIFT]);
@@ -1032,6 +1037,16 @@ __device__ __forceinline__ void binning_body(
         // (grid-stride: a small grid of a 256-thread tuning shape does not cover the 8200 16-byte words with one store per thread)
         for (uint32_t i = blockIdx.x * THREADS + tid; i < HIST_WORDS / 4; i += gridDim.x * THREADS)
             reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
+    }
+    if (mode & 512u) {
+        // A sort that was offered the two-level plan and runs on the LSD passes after all (PF_POS is set): the histogram kernel zeroed
+        // only the descriptor regions both plans use (passes 0 and 1); this launch — LSD pass 1 — zeroes the regions of passes 2 and 3
+        // beside its own work (they lie behind its own region; nobody touches them before pass 2 starts).
+        if (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) {
+            const uint32_t stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_DSTRIDE]);
+            uint4* z = reinterpret_cast<uint4*>(desc + stride);
+            for (uint32_t i = blockIdx.x * THREADS + tid; i < stride / 2u; i += gridDim.x * THREADS) z[i] = uint4{0u, 0u, 0u, 0u};  // 2 x stride words
+        }
     }
     if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
         const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
@@ -1371,12 +1386,42 @@ __device__ __forceinline__ void binning_body(
             const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return PK ? (r >> wsh) & 0xffffu : r;
         };
-        if (GS_LIKELY((pflags & PF_SKEW) == 0u && full)) {  // uniform per pass (set by scan_kernel)
+        // Crowded waves: presorted or clustered input puts the SAME digit in most lanes of a wave (a sorted tile holds one or two
+        // values of every byte above its own span) although no digit dominates the pass as a whole (PF_SKEW is clear) — and 64
+        // lanes on one LDS counter are served one after the other: 1.10 ms per pass on sorted keys against 0.43 (profiles/
+        // r05_sorted_inputs.txt).  One probe per wave and tile (its first and its last key round): a wave that finds >= 16 lanes on
+        // the first lane's digit ranks the whole tile with the first lane's digit aggregated — those lanes take ballot ranks on top of
+        // ONE add of their count by their first lane, every other lane adds for itself in the same instruction (different
+        // counters: nothing changes for them, and ranks stay in lane order, i.e. stable).
+        bool crowded = false;  // wave-uniform
+        if ((pflags & PF_SKEW) == 0u && full) {
+            const uint32_t da = (key[0] >> shift) & 255u, db = (key[KPT - 1] >> shift) & 255u;
+            crowded = __popcll(__builtin_amdgcn_ballot_w64(da == (uint32_t)__builtin_amdgcn_readfirstlane((int)da))) >= 16 ||
+                      __popcll(__builtin_amdgcn_ballot_w64(db == (uint32_t)__builtin_amdgcn_readfirstlane((int)db))) >= 16;
+        }
+        if (GS_LIKELY((pflags & PF_SKEW) == 0u && full && !crowded)) {  // uniform per pass (set by scan_kernel)
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t d = (key[i] >> shift) & 255u;
                 const uint32_t r = rank_add(d);
                 offp[i >> 1] |= r << (16 * (i & 1));
+            }
+        } else if ((pflags & PF_SKEW) == 0u && full) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(d == f);  // (lane 0 is in it)
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const bool in_m = d == f;
+                uint32_t r = 0;
+                if (!in_m || below == 0u) {
+                    const uint32_t inc = in_m ? (uint32_t)__popcll(m) : 1u;
+                    const uint32_t w = __hip_atomic_fetch_add(&whist[d], inc << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    r = PK ? (w >> wsh) & 0xffffu : w;
+                }
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(m));
+                offp[i >> 1] |= (in_m ? base + below : r) << (16 * (i & 1));
             }
         } else if ((pflags & PF_SKEW) == 0u) {
             // Partial tile: the dummies behind the segment take no part at all (mask_tail below).  Ranked like

@@ -13,11 +13,14 @@ import gpusorting_amd as g  # noqa: E402
 
 def main():
     args = sys.argv[1:]
-    flags, preset, sizes = [0], 0, []
+    flags, preset, sizes, inp = [0], 0, [], "generator"
     i = 0
     while i < len(args):
         if args[i] == "--flags":
             flags = [int(x, 0) for x in args[i + 1].split(",")]
+            i += 2
+        elif args[i] == "--input":   # generator | sorted | reverse | clustered (every 2^20 positions share their top byte)
+            inp = args[i + 1]
             i += 2
         elif args[i] == "--preset":
             preset = int(args[i + 1])
@@ -34,6 +37,11 @@ def main():
             runs = []
             for it in range(9):
                 g.init_random(dk, 10 + it, preset)
+                if inp in ("sorted", "reverse"):
+                    dk = torch.sort(dk.to(torch.int64) & 0xFFFFFFFF, descending=inp == "reverse").values.to(torch.int32)
+                elif inp == "clustered":
+                    idx = torch.arange(n, dtype=torch.int32, device="cuda")
+                    dk = ((dk & 0x00FFFFFF) | (((idx >> 20) * 37 & 0xFF) << 24)).contiguous()
                 s.sort(dk)
                 p = s.get_profile()
                 if it >= 1:
@@ -42,7 +50,7 @@ def main():
                     assert g.validate(dk) == 0, "not sorted"
             runs.sort(key=lambda r: r["total"])
             med = runs[len(runs) // 2]
-            print(f"2^{log2n} preset {preset + 1} plan={plan} flags={fl:#x}: median " + " ".join(f"{k}={v:.4f}" for k, v in med.items()) +
+            print(f"2^{log2n} {inp} preset {preset + 1} plan={plan} flags={fl:#x}: median " + " ".join(f"{k}={v:.4f}" for k, v in med.items()) +
                   f" -> {n / med['total'] / 1e6:.1f} GKeys/s (best {n / runs[0]['total'] / 1e6:.1f}) {s.last_plan()}", flush=True)
             s.close()
 
