@@ -54,7 +54,9 @@ void launch_bin(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* 
 }
 // the two-round form of the 8-byte-value pass (two workgroups per CU), launched beside the one-round form in full
 // sorts; the pass's PF_SKEW flag decides on the device which of the two works.  [rank mode][key type]
-#ifdef GS_MINIMAL  // experiment builds (tools/): u32 keys-only kernels of the three product shapes, nothing else — a 10 s compile
+#if defined(GS_MINIMAL) && defined(GS_MIN_PAIRS)
+const BinLauncher g_vr2[2][3] = {{nullptr, nullptr, nullptr}, {launch_bin<512, 32, 8, 0, 1, 2>, nullptr, nullptr}};
+#elif defined(GS_MINIMAL)  // experiment builds (tools/): u32 keys-only kernels of the three product shapes, nothing else — a 10 s compile
 const BinLauncher g_vr2[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 #else
 const BinLauncher g_vr2[2][3] = {{launch_bin<512, 32, 8, 0, 0, 2>, launch_bin<512, 32, 8, 1, 0, 2>, launch_bin<512, 32, 8, 2, 0, 2>},
@@ -83,10 +85,26 @@ void launch_posv(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void*
     hipLaunchKernelGGL((gs::digit_binning_posv_kernel<VB, KT, LAST>), dim3(grid), dim3(512), 0, s, ka, kb, va, vb, desc, counters, info,
                        hsub, status, n, shift, mode);
 }
+// pairs on the two-level plan: the plain form of the pass as persistent workgroups [8-byte values][key type]; rank mode 1 only
+template <int T, int K, int VB, int KT>
+void launch_persist(hipStream_t s, uint32_t grid, uint32_t* ka, uint32_t* kb, void* va, void* vb, uint32_t* desc, uint32_t* counters,
+                    const uint32_t* info, uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift, uint32_t mode) {
+    hipLaunchKernelGGL((gs::digit_binning_persist_kernel<T, K, VB, KT, 1>), dim3(grid), dim3(T), 0, s, ka, kb, va, vb, desc, counters, info, hsub,
+                       status, n, shift, mode);
+}
 #ifdef GS_MINIMAL
 const BinLauncher g_dual[2][3] = {{launch_dual<0, false>, nullptr, nullptr}, {launch_dual<0, true>, nullptr, nullptr}};
-const BinLauncher g_posv[2][2][3] = {{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}};
+#ifdef GS_MIN_PAIRS
+const BinLauncher g_posv[2][2][3] = {{{launch_posv<4, 0, false>, nullptr, nullptr}, {launch_posv<4, 0, true>, nullptr, nullptr}},
+                                     {{launch_posv<8, 0, false>, nullptr, nullptr}, {launch_posv<8, 0, true>, nullptr, nullptr}}};
+const BinLauncher g_persist[2][3] = {{launch_persist<1024, 16, 4, 0>, nullptr, nullptr}, {launch_persist<512, 32, 8, 0>, nullptr, nullptr}};
 #else
+const BinLauncher g_posv[2][2][3] = {{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}};
+const BinLauncher g_persist[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+#endif
+#else
+const BinLauncher g_persist[2][3] = {{launch_persist<1024, 16, 4, 0>, launch_persist<1024, 16, 4, 1>, launch_persist<1024, 16, 4, 2>},
+                                     {launch_persist<512, 32, 8, 0>, launch_persist<512, 32, 8, 1>, launch_persist<512, 32, 8, 2>}};
 // pairs: the position-chain form of the pass, launched beside the plain form(s) [4- / 8-byte values][last pass][key type]
 const BinLauncher g_posv[2][2][3] = {{{launch_posv<4, 0, false>, launch_posv<4, 1, false>, launch_posv<4, 2, false>},
                                       {launch_posv<4, 0, true>, launch_posv<4, 1, true>, launch_posv<4, 2, true>}},
@@ -129,7 +147,11 @@ struct Shape {
 #define GS_U32ONLY(T, K) {T, K, {GS_ROWS_U32(T, K, 0), GS_ROWS_U32(T, K, 1)}}
 
 #ifdef GS_MINIMAL
+#ifdef GS_MIN_PAIRS  // (tuning flavour with the uint32-key pairs kernels as well: the two-level plan for pairs, tools/)
+#define GS_ROWS_KEYS64(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}, {launch_bin<T, K, 4, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}, {launch_bin<T, K, 8, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}}
+#else
 #define GS_ROWS_KEYS64(T, K, R) {{launch_bin<T, K, 0, 0, R>, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}}
+#endif
 #define GS_KEYSONLY64(T, K) {T, K, {GS_ROWS_KEYS64(T, K, 0), GS_ROWS_KEYS64(T, K, 1)}}
 const Shape g_shapes[] = {GS_KEYSONLY64(512, 32), GS_KEYSONLY64(1024, 16), GS_KEYSONLY64(512, 16),
 #ifdef GS_TUNING
@@ -233,7 +255,25 @@ const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, launch_h
 #ifdef GS_TUNING  // other shapes of the 6144-key class (debug_flags & 7 = 1, 2; u32 keys)
 const HyLocalLauncher g_hy_local_alt[2] = {launch_hy_local<0, 256, 24>, launch_hy_local<0, 1024, 6>};
 #endif
+using HyLocalPairsLauncher = void (*)(hipStream_t, uint32_t* keys, void* vals, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending);
+template <int KT, int VB, int T, int K>
+void launch_hy_local_pairs(hipStream_t s, uint32_t* keys, void* vals, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending) {
+    hipLaunchKernelGGL((gs::hy_local_sort_pairs_kernel<KT, VB, T, K>), dim3(gs::HY_BINS), dim3(T), 0, s, keys, vals, tab, slab, n, descending);
+}
+// [8-byte values][class][key type]; the 24 576-pair class with 8-byte values does not fit a workgroup's LDS (nullptr: LSD passes)
+#define GS_HYP_ROW(VB, T, K) {launch_hy_local_pairs<0, VB, T, K>, launch_hy_local_pairs<1, VB, T, K>, launch_hy_local_pairs<2, VB, T, K>}
+#define GS_HYP_ROW0(VB, T, K) {launch_hy_local_pairs<0, VB, T, K>, nullptr, nullptr}
+#if defined(GS_MINIMAL) && defined(GS_MIN_PAIRS)
+const HyLocalPairsLauncher g_hy_local_pairs[2][4][3] = {{GS_HYP_ROW0(4, 256, 12), GS_HYP_ROW0(4, 512, 12), GS_HYP_ROW0(4, 1024, 12), GS_HYP_ROW0(4, 1024, 24)},
+                                                        {GS_HYP_ROW0(8, 256, 12), GS_HYP_ROW0(8, 512, 12), GS_HYP_ROW0(8, 1024, 12), {nullptr, nullptr, nullptr}}};
+#elif defined(GS_MINIMAL)
+const HyLocalPairsLauncher g_hy_local_pairs[2][4][3] = {};
+#else
+const HyLocalPairsLauncher g_hy_local_pairs[2][4][3] = {{GS_HYP_ROW(4, 256, 12), GS_HYP_ROW(4, 512, 12), GS_HYP_ROW(4, 1024, 12), GS_HYP_ROW(4, 1024, 24)},
+                                                        {GS_HYP_ROW(8, 256, 12), GS_HYP_ROW(8, 512, 12), GS_HYP_ROW(8, 1024, 12), {nullptr, nullptr, nullptr}}};
+#endif
 inline int hy_class(uint32_t n) { return n <= g_hy_class[0].max_n ? 0 : n <= g_hy_class[1].max_n ? 1 : n <= g_hy_class[2].max_n ? 2 : 3; }
+constexpr uint32_t HY_MIN_PAIRS_DEFAULT = (1u << 25) + 1u;  // pairs: from where the position-chain plan (its fall-back) starts — at 2^25 pairs the two-level plan already wins (61.6 against 58.8, 44.6 against 40.4 GKeys/s with 4- / 8-byte values), at 2^24 it loses
 constexpr uint32_t HY_MIN_KEYS_DEFAULT = 3u << 24;  // 50 M keys: measured, the LSD passes win at 2^25 (121 against 102 GKeys/s), the two-level plan at 2^26 (139 against 122): below, its 65 536 buckets are a few hundred keys each and a workgroup per bucket is mostly launch (profiles/r05_two_level_threshold.txt)
 
 }  // namespace
@@ -629,8 +669,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     // Two-level plan (hybrid_kernels.hpp): keys-only sorts of 32-bit keys that may also run on position chains (its fall-back when
     // the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
     // (position_chains = 2 asks for the position-chain plan whatever the keys look like: only plan 2 overrides that)
-    const bool hy = pos && vb == 0 && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
-                    (h->plan == 2 || (n >= h->hy_min_keys && h->pos_chains != 2)) &&
+    const bool hy = pos && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
+                    (h->plan == 2 || (n >= (vb ? HY_MIN_PAIRS_DEFAULT : h->hy_min_keys) && h->pos_chains != 2)) &&
+                    (vb == 0 || (g_persist[vb == 8][kt] != nullptr && g_hy_local_pairs[vb == 8][hy_class(n)][kt] != nullptr)) &&
                     (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, POS_TILE) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
@@ -676,17 +717,34 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                     // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is)
                     if (!(h->debug_flags & 0x40000000u)) local(s, gs::HY_BINS, k[0], h->hy_tab, h->slab, n, desc_bit);
                 }
+            } else if (hy) {
+                // pairs that may run on the two-level plan: launches 0 and 1 = its two DigitBinningPasses (the plain form as persistent
+                // workgroups: digit and chain count from the info block) or, on position chains, LSD passes 0 and 1 (the position-chain
+                // form, which also serves LSD passes 2 and 3); the bucket-local sort sits between them.  The non-persistent plain forms
+                // are not launched at all: whichever plan the device picks, one of these two forms is the one that works.
+                uint32_t* d_p = h->slab + SLAB_DESC + (size_t)p * plan.desc_stride;
+                uint32_t* c_p = h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE;
+                const uint32_t* i_p = h->slab + SLAB_INFO + p * gs::INFO_STRIDE;
+                if (p < 2)
+                    g_persist[vb == 8][kt](s, pos_grid() / 2u, k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
+                                           p * 8, mode | 64u | 128u | 256u);
+                g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
+                                            p * 8, (mode & ~4u) | 64u | (p == 1 ? 512u : 0u));
+                if (p == 1) {
+                    if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));
+                    if (!(h->debug_flags & 0x40000000u)) g_hy_local_pairs[vb == 8][hy_class(n)][kt](s, k[0], v[0], h->hy_tab, h->slab, n, desc_bit);
+                }
             } else
                 (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
                    mode | (two_forms ? 32u : 0u) | ((pos && vb != 0) ? 64u : 0u) | exp_mode);
-            if (two_forms)
+            if (two_forms && !hy)
                 g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                         h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                         h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
                                         word * 32 + p * 8, mode | 16u | ((pos && vb == 8) ? 64u : 0u));
-            if (pos && vb != 0)  // pairs: the position-chain form is a launch of its own (the plan's flags pick one of the two or three)
+            if (pos && vb != 0 && !hy)  // pairs: the position-chain form is a launch of its own (the plan's flags pick one of the two or three)
                 g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
@@ -856,7 +914,7 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
     // the two-level plan: keys-only handles that can hold a sort of its size class (the position-chain plan, its fall-back, starts at 2^20 keys)
-    const bool hy_handle = mode == GS_MODE_KEYS_ONLY && max_keys > (1u << 20) && o.plan != 1;
+    const bool hy_handle = max_keys > (1u << 20) && o.plan != 1;
     {
         size_t slice_words = (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS;
         if (hy_handle && (size_t)h->hy_grid * gs::HY_SLICE_WORDS > slice_words) slice_words = (size_t)h->hy_grid * gs::HY_SLICE_WORDS;
@@ -926,7 +984,7 @@ gs_status gs_onesweep_set_plan(gs_onesweep* h, int plan) {
     h->ls_plan = 0;
 #endif
     if (plan > 2) return GS_ERR_ARG;
-    if (plan == 2 && !h->hy_tab) return GS_ERR_MODE;  // (the handle was created without the plan's tables: pairs, max_keys <= 2^20, or plan 1 at create)
+    if (plan == 2 && !h->hy_tab) return GS_ERR_MODE;  // (the handle was created without the plan's tables: max_keys <= 2^20, or plan 1 at create)
     h->plan = plan;
     return GS_OK;
 }

@@ -19,7 +19,8 @@
 //                         — both are the SAME kernels as the LSD passes (binning_body), told their digit and chain count by the
 //                         info block — and
 //   hy_local_sort_kernel  one workgroup per 16-bit-prefix bucket (n / 65 536 keys on average): loads the bucket, sorts it on the low
-//                         16 bits by two stable 8-bit passes in LDS, and writes it back IN PLACE — sequential reads and writes.
+//                         16 bits by two 8-bit passes in LDS, and writes it back IN PLACE — sequential reads and writes
+//                         (hy_local_sort_pairs_kernel: the same with values, which move once, behind the keys).
 // (stable by byte 3) o (stable by byte 2 inside each byte-3 bucket) o (stable by the low 16 bits inside each 16-bit bucket) is
 // the stable sort by the whole key: the result is bit-identical to the four LSD passes, values included.
 //
@@ -568,6 +569,123 @@ __global__ __launch_bounds__(THREADS_) void hy_local_sort_kernel(uint32_t* keys,
     for (int i = 0; i < KPT; ++i) {
         const uint32_t slot = my_base + i * 64u;
         if ((uint32_t)i < kpt && slot < count) keys[at + (descending ? count - 1u - slot : slot)] = from_bits<KT>(s_stage[slot]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same for (key, value) pairs.  Stable in BOTH passes (values make equal keys distinguishable: the result must be the stable
+// sort's, SortCommon.hlsl:594-597 for descending: its exact reverse).  The values do not travel through the two LDS passes:
+// every key of the bucket shares its top 16 bits (= blockIdx.x), so those bits carry the key's ORIGINAL SLOT instead — the
+// sorted element at slot j is (slot of origin << 16 | low 16 bits) — and the values move once, at the end: written to the stage
+// by their owners in slot order, read back through the sorted elements' origin slots (one 4- / 8-byte LDS write and read per
+// value instead of two each).  The stage of the values re-uses the keys' stage.
+// ---------------------------------------------------------------------------
+template <int KT, int VB, int THREADS_, int KPT_>
+__global__ __launch_bounds__(THREADS_) void hy_local_sort_pairs_kernel(uint32_t* keys, void* vals_, const uint32_t* __restrict__ tab,
+                                                                       const uint32_t* __restrict__ slab, uint32_t n, uint32_t descending) {
+    using V = typename ValT<VB>::type;
+    constexpr int KPT = KPT_, WAVES = THREADS_ / 64;
+    constexpr uint32_t THREADS = THREADS_, TILE = THREADS_ * KPT_;
+    static_assert(THREADS >= RADIX && KPT % 2 == 0 && WAVES % 2 == 0 && TILE < 65536, "slots of origin and counters are 16-bit fields");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[TILE * (VB > 4 ? VB : 4)];
+    __shared__ uint32_t s_cnt[WAVES / 2 * RADIX];
+    __shared__ uint32_t s_wtot[4];
+    uint32_t* s_stage = reinterpret_cast<uint32_t*>(s_raw);
+    V* s_vstage = reinterpret_cast<V*>(s_raw);
+    V* vals = reinterpret_cast<V*>(vals_);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t valid = slab[SLAB_HY + HY_VALID], b_lo = tab[HYT_BASE + blockIdx.x], b_hi = tab[HYT_BASE + blockIdx.x + 1u];
+    if (__builtin_amdgcn_readfirstlane((int)valid) == 0) return;  // the sort runs on the LSD passes
+    const uint32_t start = b_lo, count = b_hi - b_lo;
+    if (count == 0u || count > TILE || start > n || count > n - start) return;
+    // descending: pass B wrote to mirrored positions — the bucket lies at [n - start - count, n - start) in REVERSE arrival order;
+    // slot s is read from (and, sorted, written to) position count - 1 - s of that range
+    const uint32_t at = descending ? n - start - count : start;
+    const uint32_t kpt = (uint32_t)__builtin_amdgcn_readfirstlane((int)((count + THREADS - 1u) / THREADS));  // uniform, 1 .. KPT
+    const uint32_t my_base = wave * (64u * kpt) + lane;
+    uint32_t key[KPT];
+    V val[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;  // uniform
+        const uint32_t slot = my_base + i * 64u, cs = slot < count ? slot : count - 1u;
+        const uint32_t pos = at + (descending ? count - 1u - cs : cs);
+        key[i] = keys[pos];
+        val[i] = vals[pos];
+    }
+    const uint32_t wsh = (uint32_t)__builtin_amdgcn_readfirstlane((int)((wave & 1u) * 16u));
+    uint32_t* wh = s_cnt + (wave >> 1) * RADIX;
+    // element = slot of origin << 16 | low 16 bits of the (radix-sortable) key
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+        if ((uint32_t)i < kpt) key[i] = (to_bits<KT>(key[i]) & 0xffffu) | ((my_base + i * 64u) << 16);
+    uint32_t off[KPT / 2];
+#pragma unroll 1
+    for (uint32_t shift = 0; shift < 16; shift += 8) {
+        for (uint32_t i = tid; i < WAVES / 2 * RADIX; i += THREADS) s_cnt[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT / 2; ++i) off[i] = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
+            if (my_base + i * 64u < count) {
+                const uint32_t r = __hip_atomic_fetch_add(&wh[(key[i] >> shift) & 255u], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                off[i >> 1] |= ((r >> wsh) & 0xffffu) << (16 * (i & 1));
+            }
+        }
+        __syncthreads();
+        uint32_t run = 0, scan_incl = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int p = 0; p < WAVES / 2; ++p) {
+                const uint32_t c2 = s_cnt[p * RADIX + tid];
+                s_cnt[p * RADIX + tid] = run | ((run + (c2 & 0xffffu)) << 16);
+                run += (c2 & 0xffffu) + (c2 >> 16);
+            }
+            scan_incl = wave_inclusive_scan_dpp(run);
+            if (lane == 63) s_wtot[wave] = scan_incl;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < wave; ++w) wbase += s_wtot[w];
+            const uint32_t dpre = wbase + scan_incl - run;
+#pragma unroll
+            for (int p = 0; p < WAVES / 2; ++p) s_cnt[p * RADIX + tid] += dpre * 0x10001u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
+            if (my_base + i * 64u < count)
+                s_stage[((off[i >> 1] >> (16 * (i & 1))) & 0xffffu) + ((wh[(key[i] >> shift) & 255u] >> wsh) & 0xffffu)] = key[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            if ((uint32_t)i >= kpt) continue;
+            key[i] = s_stage[my_base + i * 64u];  // (slots >= count: masked wherever they are used)
+        }
+        // (the next pass zeroes the counters and crosses a barrier before anything writes the stage again)
+    }
+    // key[i] is now the sorted element of slot my_base + i * 64: its key goes out; its value is the one of its slot of origin
+    __syncthreads();  // everybody has read the stage: it becomes the values' stage
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if ((uint32_t)i >= kpt) continue;
+        if (my_base + i * 64u < count) s_vstage[my_base + i * 64u] = val[i];
+    }
+    __syncthreads();
+    const uint32_t top = blockIdx.x << 16;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t slot = my_base + i * 64u;
+        if ((uint32_t)i < kpt && slot < count) {
+            const uint32_t pos = at + (descending ? count - 1u - slot : slot);
+            keys[pos] = from_bits<KT>(top | (key[i] & 0xffffu));
+            vals[pos] = s_vstage[key[i] >> 16];
+        }
     }
 }
 

@@ -1988,6 +1988,17 @@ __global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::va
                                                            shift_full, mode);
 }
 
+// The plain form as PERSISTENT workgroups (as many as fit a CU): the two DigitBinningPasses of the two-level plan for pairs — its
+// second pass walks 256 chains group by group, which a workgroup does across its tiles (binning_body, `group`).
+template <int THREADS, int KPT, int VB, int KT, int RANK, int VR = 1>
+__global__ __launch_bounds__(THREADS, (BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::WAVES_PER_SIMD)) void digit_binning_persist_kernel(
+    uint32_t* keys_a, uint32_t* keys_b, void* vals_a, void* vals_b, uint32_t* desc, uint32_t* counters, const uint32_t* info,
+    uint32_t* hsub, uint32_t* status, uint32_t n, uint32_t shift_full, uint32_t mode) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[BinCfg<THREADS, KPT, VB, KeyWords<KT>::value, VR>::LDS_BYTES];
+    binning_body<THREADS, KPT, VB, KT, RANK, VR, 0, true>(s_raw, keys_a, keys_b, vals_a, vals_b, desc, counters, info, hsub, status, n,
+                                                          shift_full, mode);
+}
+
 // Keys-only sorts of 32-bit keys that the Scan kernel MAY plan on position chains (PF_POS, decided on the device from what the
 // histogram kernel saw): ONE launch per pass serves both plans — persistent workgroups, two per CU, that run the plain form of
 // the pass (512 x 32 tiles, chains as planned) or, under PF_POS, its position-chain form on the same tiles: with the (packed) next-digit

@@ -97,7 +97,7 @@ typedef struct gs_onesweep_options {
                                         groups uneven, 0 never, 2 always (tests, tuning) */
     uint32_t position_chains_min_log2;  /* ... from 2^this + 1 keys up (default 25; 20 .. 30) */
     int32_t key64_sweeps;            /* 64-bit keys: 1 (default) one histogram sweep plans all eight passes, 2 one sweep per word */
-    int32_t plan;                    /* gs_onesweep_set_plan: 0 (default) the library picks — the two-level plan for large keys-only sorts whose
+    int32_t plan;                    /* gs_onesweep_set_plan: 0 (default) the library picks — the two-level plan for large sorts whose
                                         keys turn out near-uniform, the four LSD passes otherwise; 1 LSD passes only; 2 two-level plan wherever it can run */
     int32_t first_pass_big;          /* 1 (default): keys-only mid sizes run their first pass on the 16 384-key tile */
     uint32_t hist_blocks;            /* workgroups of the GlobalHistogram kernel; 0 (default) = one per CU (tuning aid) */
@@ -176,7 +176,7 @@ gs_status gs_onesweep_set_mid_path(gs_onesweep* h, int on);
  * four passes).  Results are identical either way; 0 runs all four passes.  Default 1;
  * (gs_onesweep_options::skip_passes at create). */
 gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
-/* Plan of large keys-only sorts of 32-bit keys (library-picked shape, rank mode 1, position chains allowed).
+/* Plan of large sorts of 32-bit keys — keys-only and pairs (library-picked shape, rank mode 1, position chains allowed).
  * The reference's pipeline is GlobalHistogram + Scan + four 8-bit LSD DigitBinningPasses (GPUSortingCUDA/Sort/OneSweep.cu:44-344,
  * dispatch OneSweepDispatcher.cuh:311-336): 36 bytes of memory traffic per key.  The TWO-LEVEL plan (hybrid_kernels.hpp) runs the same
  * kernels in another order — one histogram sweep over the keys' top 16 bits, a Scan, a DigitBinningPass on the top byte, a
@@ -184,9 +184,10 @@ gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
  * 16 bits in LDS, in place: 28 bytes per key, the same result bit for bit.  It needs buckets that fit a workgroup (near-uniform top
  * 16 bits); whether they do is decided ON THE DEVICE from the histogram (no host round trip): otherwise the same launches run the
  * four LSD passes on position chains.
- *   0 (default): the two-level plan is offered from 3 x 2^24 (50 M) keys up;  1: never (the LSD passes only);  2 (tests): offered at every
- *   size from gs_onesweep_options::position_chains_min_log2 up.  GS_ERR_MODE for 2 on a handle without the plan's tables (pairs,
- *   max_keys <= 2^20, or created with plan 1).
+ *   0 (default): the two-level plan is offered from 3 x 2^24 (50 M) keys up, to pairs from 2^25 + 1 (measured crossovers);  1: never (the
+ *   LSD passes only);  2 (tests): offered at every size from gs_onesweep_options::position_chains_min_log2 up.  GS_ERR_MODE for 2 on a
+ *   handle without the plan's tables (max_keys <= 2^20, or created with plan 1).  Pairs: the values travel with their keys through
+ *   both DigitBinningPasses and are moved once more by the bucket-local sort — 52 / 76 bytes per pair instead of 68 / 100.
  * gs_onesweep_last_plan (synchronous) reports what the device decided for the last sort: *plan = 1 the two-level plan ran, 0 the LSD
  * passes (or a one- / two-launch route); *largest_bucket (may be NULL) = the largest 16-bit-prefix bucket it saw (0 if not offered). */
 gs_status gs_onesweep_set_plan(gs_onesweep* h, int plan);

@@ -262,3 +262,33 @@ def test_2pow28_few_valued_bytes_packed_counter_guard(gpu, values):
     s.check()
     assert bool(torch.equal(dk.to(torch.int64) & 0xFFFFFFFF, want))
     s.close()
+
+
+@pytest.mark.parametrize("kind", ["sorted", "reverse_sorted", "block_clustered"])
+def test_2pow28_presorted_and_clustered_inputs_exact(gpu, oracle, kind):
+    """inputs the entropy presets do not cover, at the headline size, bit-exact.  Sorted and reverse-sorted keys (every
+    wave of a tile holds ONE value of the upper bytes: the crowded-wave ranking of binning_body; every 4096-key chunk of the histogram
+    sweep lies under one prefix) and block-clustered keys (2^20 consecutive positions share their top byte).  All three are
+    near-uniform in their top 16 bits, so the device runs the two-level plan."""
+    import torch
+    n = 1 << 28
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, 2828, 0)
+    s = gpu.OneSweep(n)
+    if kind == "block_clustered":
+        idx = torch.arange(n, dtype=torch.int32, device="cuda")
+        dk = ((dk & 0x00FFFFFF) | (((idx >> 20) * 37 & 0xFF) << 24)).contiguous()
+        del idx
+        keys = dk.cpu().numpy().view(np.uint32)
+        want = torch.from_numpy(oracle.std_sort_parallel(keys, oracle.hardware_threads()).view(np.int32)).cuda()
+    else:
+        s.sort(dk)                        # (a sorted array to start from; its own exactness is test_2pow28_keys_exact_vs_oracle's business)
+        assert gpu.validate(dk) == 0
+        want = dk.clone()
+        if kind == "reverse_sorted":
+            dk = torch.flip(dk, dims=(0,)).contiguous()
+    s.sort(dk)
+    s.check()
+    assert s.last_plan()["two_level"]
+    assert bool((dk == want).all().item()), f"{kind}: result differs"
+    s.close()

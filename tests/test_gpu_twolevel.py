@@ -119,10 +119,68 @@ def test_two_level_plan_needs_its_tables(gpu):
     s.set_plan(0)
     s.set_plan(1)
     s.close()
-    p = gpu.OneSweep(MAXK, mode=gpu.MODE_PAIRS, value_bytes=4)
+    p = gpu.OneSweep(MAXK, plan=1)
     with pytest.raises(Exception):
-        p.set_plan(2)      # pairs
+        p.set_plan(2)      # created with plan 1: no tables
     p.close()
+
+
+# ---- pairs: the values go through both DigitBinningPasses with their keys and once more through the bucket-local sort ------------
+@pytest.fixture(scope="module")
+def pair_sorters(gpu):
+    made = {}
+
+    def get(vb, kt, order):
+        if (vb, kt, order) not in made:
+            made[(vb, kt, order)] = gpu.OneSweep(MAXK, order, kt, gpu.MODE_PAIRS, vb, small_path=0, mid_path=0, plan=2, position_chains_min_log2=20)
+        return made[(vb, kt, order)]
+    yield get
+    for s in made.values():
+        s.close()
+
+
+@pytest.mark.parametrize("n", [(1 << 20) + 7, 3 * 16384 * 37, (1 << 23) + 4321])
+@pytest.mark.parametrize("vb,kt,order", [(4, 0, 0), (4, 2, 1), (8, 0, 0), (8, 1, 1), (8, 0, 1)])
+def test_two_level_plan_pairs_stable(gpu, oracle, pair_sorters, n, vb, kt, order):
+    """value = original index, keys with many duplicates in their low bytes (masked to 20 significant bits spread over the word):
+    keys AND the order of the values must be the stable sort's (descending: its exact reverse), on the two-level plan and on the LSD
+    passes alike."""
+    import torch
+    s = pair_sorters(vb, kt, order)
+    k = _keys(oracle, n, n & 0xFFFF | 1, 0, "uniform") & np.uint32(0xFFF00FFF if (n % 2 and kt != 2) else 0xFFFFFFFF)   # (odd n: 256-fold duplicates inside every bucket)
+    if kt == 2:   # (NaN patterns sort by bits in both; folding them onto finite exponents of MASKED keys would double two prefixes past the bucket limit)
+        k = np.where((k & 0x7F800000) == 0x7F800000, k & ~np.uint32(0x00800000), k).astype(np.uint32)
+    v = np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+    wk, wv = oracle.std_sort(k, kt, order, v)
+    for plan in (2, 1):
+        s.set_plan(plan)
+        dk = to_dev(k.copy())
+        dv = torch.from_numpy(v.view(np.int32 if vb == 4 else np.int64).copy()).cuda()
+        s.sort(dk, dv)
+        s.check()
+        assert s.last_plan()["two_level"] == (plan == 2)
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), wk, err_msg=f"plan {plan}")
+        np.testing.assert_array_equal(dv.cpu().numpy().view(v.dtype), wv, err_msg=f"plan {plan}")
+
+
+@pytest.mark.parametrize("vb", [4, 8])
+@pytest.mark.parametrize("kind,andc,two_level", [("uniform", 2, False), ("high16", 0, True), ("sorted", 0, True), ("blocks", 0, True), ("bigbucket", 0, False)])
+def test_two_level_plan_pairs_distributions(gpu, oracle, pair_sorters, vb, kind, andc, two_level):
+    import torch
+    n = (1 << 22) + 12345
+    k = _keys(oracle, n, 78, andc, kind)
+    v = np.arange(n, dtype=np.uint32 if vb == 4 else np.uint64)
+    for order in (0, 1):
+        s = pair_sorters(vb, 0, order)
+        s.set_plan(2)
+        wk, wv = oracle.std_sort(k, 0, order, v)
+        dk = to_dev(k.copy())
+        dv = torch.from_numpy(v.view(np.int32 if vb == 4 else np.int64).copy()).cuda()
+        s.sort(dk, dv)
+        s.check()
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), wk)
+        np.testing.assert_array_equal(dv.cpu().numpy().view(v.dtype), wv)
+        assert s.last_plan()["two_level"] == two_level, (kind, s.last_plan())
 
 
 def test_two_level_plan_in_a_hip_graph(gpu, oracle, sorters):
