@@ -60,7 +60,8 @@ def onesweep_options_from_env(**overrides) -> "OneSweepOptions":
                         ("GPUSORT_LS_EXP", "debug_flags"), ("GPUSORT_EXPMODE", "debug_flags")):
         if name in env:
             try:
-                setattr(o, field, int(env[name], 0))
+                v = int(env[name], 0)
+                setattr(o, field, (getattr(o, field) | v) if field == "debug_flags" else v)  # (two variables feed debug_flags: their bits add up)
             except ValueError:
                 pass
     _apply_overrides(o, overrides)

@@ -882,7 +882,11 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->mid_path = o.mid_path ? 1 : 0;
     h->hist_blocks_opt = o.hist_blocks;
     h->first_pass_big = o.first_pass_big ? 1 : 0;
+#if defined(GS_TUNING) || GS_EXP
     h->debug_flags = o.debug_flags;
+#else
+    h->debug_flags = o.debug_flags & 0x40000000u;  // the product build knows one bit (bring-up aid: skip the bucket-local sort); everything else belongs to tuning / experiment builds
+#endif
     h->profiling = 0;
     h->ev_valid = false;
     h->profile_pending = false;

@@ -139,11 +139,13 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
             since_fold = 0;
         }
         ++since_fold;
+#ifndef GS_HY_ABL_NO_REPLICA  // (ablation: what the digit-0 counts cost)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t d = b[j] & 255u;
             atomicAdd(&s_r[(d >> 1) * 32u + (lane & 31u)], 1u << ((d & 1u) * 16u));
         }
+#endif
         if (joint_off) return;  // uniform
         if (probe) {
             const uint32_t p0 = b[0] >> 16;
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(HY_HIST_THREADS, HY_HIST_THREADS / 256) void hy_his
         }
     };
     // One work item = 4 consecutive chunks; all their 16-byte loads are issued before the first is consumed.
-    constexpr uint32_t UNROLL = 4;
+#ifndef GS_HY_HIST_UNROLL
+#define GS_HY_HIST_UNROLL 4
+#endif
+    constexpr uint32_t UNROLL = GS_HY_HIST_UNROLL;
     for (uint32_t c0 = begin; c0 < end; c0 += UNROLL * HIST_CHUNK) {
         if ((unsigned long long)c0 + UNROLL * HIST_CHUNK <= end) {
             uint4 t[UNROLL];

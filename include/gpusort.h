@@ -95,13 +95,15 @@ typedef struct gs_onesweep_options {
     int32_t skip_passes;             /* 1 (default): identity passes (a constant byte) are dropped in pairs on the device */
     int32_t position_chains;         /* skewed keys: 1 (default) position-chain plan when the histogram kernel finds the digit
                                         groups uneven, 0 never, 2 always (tests, tuning) */
-    uint32_t position_chains_min_log2;  /* ... from 2^this + 1 keys up (default 25; 20 .. 30) */
+    uint32_t position_chains_min_log2;  /* ... from 2^this keys up (20 .. 30); the default, 25, means 2^25 + 1: up to 2^25 keys the smaller tile shape wins */
     int32_t key64_sweeps;            /* 64-bit keys: 1 (default) one histogram sweep plans all eight passes, 2 one sweep per word */
     int32_t plan;                    /* gs_onesweep_set_plan: 0 (default) the library picks — the two-level plan for large sorts whose
                                         keys turn out near-uniform, the four LSD passes otherwise; 1 LSD passes only; 2 two-level plan wherever it can run */
     int32_t first_pass_big;          /* 1 (default): keys-only mid sizes run their first pass on the 16 384-key tile */
     uint32_t hist_blocks;            /* workgroups of the GlobalHistogram kernel; 0 (default) = one per CU (tuning aid) */
-    uint32_t debug_flags;            /* tuning builds: extra mode bits handed to the kernels (tools/r04_ls_*.py); 0 */
+    uint32_t debug_flags;            /* 0.  Product build: bit 30 only (bring-up aid, tools/hy_bringup.py: the two-level plan stops behind its second
+                                        pass); every other bit is masked off.  Tuning / experiment builds: bits 0-2 shape of the bucket-local sort,
+                                        bits 8-17 the round-4 local-sort plan's switches, GS_EXP builds: bits 8-11 ablation modes */
 } gs_onesweep_options;
 void gs_onesweep_options_default(gs_onesweep_options* o);
 /* gs_onesweep_create with explicit options (NULL = defaults).  GS_ERR_ARG for a struct_size this library does not know, a tile
@@ -327,7 +329,10 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* ctx, const void* d_keys, const void*
 /* Synchronises `stream` and reports the last call's outcome: GS_ERR_COMM if SOME rank carried an error of its own through the
  * exchange (every rank's status is all-gathered at the end of the call: its peers were served, its own result is not there, and
  * the global result is incomplete), otherwise gs_onesweep_check() of the local sorter.  (A rank that fails BEFORE the histogram
- * gather poisons its row instead, and every rank's gs_onesweep_sort_sharded returns GS_ERR_COMM at once.) */
+ * gather poisons its row instead, and every rank's gs_onesweep_sort_sharded returns GS_ERR_COMM at once.)  If the last
+ * gs_onesweep_sort_sharded itself returned an error on this rank, the gathered words on the device belong to an EARLIER call: nothing
+ * is read, GS_ERR_COMM is returned and the context stays marked as failed (its teardown aborts the communicators) until a later
+ * call has completed cleanly on every rank. */
 gs_status gs_mgpu_check(gs_mgpu* ctx, void* stream);
 /* Test hook: the next gs_onesweep_sort_sharded on this rank fails on its own — 1: before the histogram gather, 2: after the plan
  * (as if a HIP launch had failed) — to exercise the failure agreement with the peers.  0 clears it. */

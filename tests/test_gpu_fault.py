@@ -55,6 +55,39 @@ def test_withheld_descriptor_is_recounted_by_the_fallback(gpu):
     assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
 
 
+def test_withheld_descriptor_on_the_two_level_plan(gpu):
+    """The two-level plan's DigitBinningPasses are the same kernels (binning_body): tile 5 of chain 3 stays silent in pass A (16 position
+    chains) AND in pass B (256 chains: top-byte bucket 3 has eight tiles at 2^25 keys) — the look-back fallback recounts it, keys and
+    (stable) pairs come out exact with GS_OK.  Without the fallback the sort returns GS_ERR_TIMEOUT instead of hanging."""
+    code = """
+        import sys, time, torch
+        sys.path.insert(0, %r)
+        import gpusorting_amd as g
+        for n, pairs in (((1 << 25) + 999, False), ((1 << 25) + 5, True)):
+            k = torch.empty(n, dtype=torch.int32, device="cuda")
+            g.init_random(k, 10, 0)
+            v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+            ref = torch.sort(k.to(torch.int64) & 0xffffffff, stable=True)
+            s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0, plan=2)
+            t0 = time.time()
+            s.sort(k, v)
+            try:
+                s.check()
+            except g.GpuSortError as e:
+                print("RESULT status", e.status, "seconds", round(time.time() - t0, 3))
+                continue
+            ok = s.last_plan()["two_level"] and bool(((k.to(torch.int64) & 0xffffffff) == ref.values).all().item())
+            if pairs:
+                ok = ok and bool((v.to(torch.int64) == ref.indices).all().item())
+            print("RESULT", "exact" if ok else "WRONG", "seconds", round(time.time() - t0, 3))
+    """
+    out = _run("libgpusort_fault.so", code)
+    assert out.count("RESULT exact") == 2, out
+    out = _run("libgpusort_fault_nofallback.so", code)
+    assert out.count("RESULT status 4") == 2, out
+    assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
+
+
 def test_mid_route_adopts_the_tiles_of_absent_workgroups(gpu):
     """Round-2 review, item 2 (reference: EmulatedDeadlocking.cu:36-37,339-345): in the fault build every fourth workgroup of the
     mid-size route's first kernel behaves as if it had never been dispatched.  The others adopt its tile — counts and

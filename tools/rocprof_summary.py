@@ -27,12 +27,13 @@ def main():
             agg = {}
             for r in rows:
                 key = (r[ik][:110], r[ic])
-                a = agg.setdefault(key, [0, 0.0])
-                a[0] += 1
-                a[1] += float(r[iv])
-            print("-- PMC counters: kernel | counter | dispatches | mean value per dispatch")
-            for (k, c), (cnt, tot) in sorted(agg.items()):
-                print(f"{k:110s} | {c} | {cnt} | {tot/cnt:.1f}")
+                agg.setdefault(key, []).append(float(r[iv]))
+            # `working` = dispatches above 5 % of the kernel's largest value: a sort enqueues launches that exit on their flag word
+            # (the plan the device did not choose); they would dilute a plain mean
+            print("-- PMC counters: kernel | counter | dispatches | mean value per dispatch | working dispatches | mean over the working ones")
+            for (k, c), vals in sorted(agg.items()):
+                work = [v for v in vals if v > 0.05 * max(vals)] or vals
+                print(f"{k:110s} | {c} | {len(vals)} | {sum(vals)/len(vals):.1f} | {len(work)} | {sum(work)/len(work):.1f}")
 
 
 if __name__ == "__main__":
