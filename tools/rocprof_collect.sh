@@ -12,9 +12,12 @@ for cfg in keys pairs4 pairs8; do
   args="--steps 3 --warmup 1 --no-cpu-baseline --no-more $extra"
   rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write
   rocprofv3 --kernel-trace --stats -d /tmp/p_stats -- python $repo/bench.py $args > /tmp/p_stats.log 2>&1
+  if [ -z "${ONLY_STATS:-}" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -- python $repo/bench.py $args > /tmp/p_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -- python $repo/bench.py $args > /tmp/p_write.log 2>&1
+  fi
   { echo "### rocprofv3 --kernel-trace --stats -- python bench.py $args"; python $repo/tools/rocprof_summary.py /tmp/p_stats/*/*_results.db; grep '^{' /tmp/p_stats.log | tail -1 | cut -c1-600; } > $repo/$out/${cfg}_stats.txt 2>&1
+  [ -n "${ONLY_STATS:-}" ] && continue
   { echo "### rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py $args"; python $repo/tools/rocprof_summary.py /tmp/p_fetch/*/*_results.db; } > $repo/$out/${cfg}_fetch.txt 2>&1
   { echo "### rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python bench.py $args"; python $repo/tools/rocprof_summary.py /tmp/p_write/*/*_results.db; } > $repo/$out/${cfg}_write.txt 2>&1
 done

@@ -15,6 +15,24 @@ def main():
                 "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
             # the top_kernels view reports microseconds
             print(f"{name[:110]:110s} | {calls:5d} | {total/1e3:10.3f} | {avg:10.2f} | {pct:6.2f}")
+        # per-dispatch durations: a sort also enqueues launches that exit on their flag word (the plan the device did not choose) —
+        # `working` = dispatches above 5 % of the kernel's longest one; their mean is what bench.py's HIP events measure
+        try:
+            kc = [d[0] for d in cur.execute("select * from kernels limit 1").description]
+            nm = "name" if "name" in kc else "kernel_name"
+            if "duration" in kc:
+                q = f"select {nm}, duration from kernels"
+            else:
+                q = f"select {nm}, (end - start) from kernels"
+            per = {}
+            for name, dur in cur.execute(q):
+                per.setdefault(name[:110], []).append(float(dur))
+            print("-- per-dispatch durations (view `kernels`, ns): name | dispatches | mean_us | working dispatches | mean_us over the working ones")
+            for name, ds in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                work = [x for x in ds if x > 0.05 * max(ds)] or ds
+                print(f"{name:110s} | {len(ds):5d} | {sum(ds)/len(ds)/1e3:10.2f} | {len(work):5d} | {sum(work)/len(work)/1e3:10.2f}")
+        except Exception as e:  # noqa: BLE001
+            print(f"-- per-dispatch durations unavailable: {e}")
         try:
             cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
             rows = list(cur.execute("select * from counters_collection"))
