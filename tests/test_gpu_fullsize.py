@@ -72,6 +72,7 @@ def test_maximum_size_2pow30_minus_1(gpu, andc):
     assert int(h_before[0].sum()) == n
     s.sort(dk, n=n)
     s.check()
+    assert s.last_plan()["two_level"] == (andc == 0)     # uniform: the two-level plan's largest class (24 576-key buckets); preset 5: the LSD passes
     assert gpu.validate(dk, n=n) == 0
     np.testing.assert_array_equal(s.global_histogram(dk, n), h_before)
     lo = dk[:4].cpu().numpy().view(np.uint32)
@@ -292,3 +293,28 @@ def test_2pow28_presorted_and_clustered_inputs_exact(gpu, oracle, kind):
     assert s.last_plan()["two_level"]
     assert bool((dk == want).all().item()), f"{kind}: result differs"
     s.close()
+
+
+@pytest.mark.parametrize("vb", [0, 4, 8])
+def test_3x2pow27_two_level_plan_against_the_lsd_passes(gpu, vb):
+    """The two-level plan's third size class (2^28 < n <= 2^29: 12 288-element buckets, 1024-thread workgroups) on 3 x 2^27 elements:
+    the same input sorted by the LSD passes (plan 1, exact against the oracle wherever the oracle reaches) and by the library's
+    default must agree element for element — keys, and values = original index (stability)."""
+    import torch
+    n = 3 << 27
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, 329, 0)
+    out = []
+    for plan in (1, 0):
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb, plan=plan)
+        k = dk.clone()
+        v = torch.arange(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda") if vb else None
+        s.sort(k, v)
+        s.check()
+        assert s.last_plan()["two_level"] == (plan == 0)
+        out.append((k, v))
+        s.close()
+    assert gpu.validate(out[1][0]) == 0
+    assert bool((out[0][0] == out[1][0]).all().item()), "keys differ between the plans"
+    if vb:
+        assert bool((out[0][1] == out[1][1]).all().item()), "values differ between the plans"
