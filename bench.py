@@ -218,19 +218,22 @@ def roofline_block(n, vb, prof, log2_keys, entropy, shape, tile_keys=None, rank_
         gbs = bpk * n / (ms * 1e-3) / 1e9
         return {"kernel": name, "what": what, "algorithmic_bytes": bpk * n, "ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
 
+    pass_kernel = "digit_binning_dual_kernel" if not vb else f"digit_binning_persist_kernel<{'1024,16,4' if vb == 4 else '512,32,8'}>"
     if two_level:
         kernels = [kern("hy_histogram_kernel + hy_reduce_kernel", prof["global_histogram"], 4, "one read of the keys: 16-bit-prefix histogram (+ digit-0 counts)"),
-                   kern("digit_binning_dual_kernel (pass A)", prof["pass0"], bpk_pass, "DigitBinningPass on the top byte, 16 position chains"),
-                   kern("digit_binning_dual_kernel (pass B)", prof["pass1"], bpk_pass, "DigitBinningPass on byte 2 inside the top-byte buckets, 256 chains"),
-                   kern("hy_local_sort_kernel", prof["pass2"], bpk_pass, "one workgroup per 16-bit-prefix bucket: low 16 bits sorted in LDS, in place "
-                        "(LDS-instruction-bound; the slot includes the exit of LSD pass 2's idle launch)")]
+                   kern(pass_kernel + " (pass A)", prof["pass0"], bpk_pass, "DigitBinningPass on the top byte, 16 position chains"),
+                   kern(pass_kernel + " (pass B)", prof["pass1"], bpk_pass, "DigitBinningPass on byte 2 inside the top-byte buckets, 256 chains"),
+                   kern("hy_local_sort_kernel" if not vb else "hy_local_sort_pairs_kernel", prof["pass2"], bpk_pass,
+                        "one workgroup per 16-bit-prefix bucket: low 16 bits sorted in LDS, in place (LDS-instruction-bound; the slot includes the exit of "
+                        "LSD pass 2's idle launch)" + ("" if not vb else "; the values move once, behind the keys"))]
     else:
         kernels = [kern("global_histogram_kernel + hist_reduce_kernel", prof["global_histogram"], 4, "one read of the keys: four joint histograms")] + \
                   [kern(f"DigitBinningPass {p}", prof[f"pass{p}"], bpk_pass, "one 8-bit LSD pass") for p in range(4)]
     return {
         "bound": "hbm",
         "kernel": ("digit_binning_dual_kernel (one 8-bit DigitBinningPass per launch; persistent workgroups; plain form for even keys, "
-                   "position-chain form when the device plans PF_POS)") if not vb else "digit_binning_kernel (one 8-bit DigitBinningPass)",
+                   "position-chain form when the device plans PF_POS)") if not vb else
+                  (pass_kernel + " (one 8-bit DigitBinningPass per launch; persistent workgroups)" if two_level else "digit_binning_kernel (one 8-bit DigitBinningPass)"),
         "plan": ("two-level: histogram of the top 16 bits, DigitBinningPass on byte 3, DigitBinningPass on byte 2 (256 chains), bucket-local LDS sort "
                  "of the low 16 bits — chosen on the device") if two_level else "GlobalHistogram + Scan + four LSD DigitBinningPasses",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
