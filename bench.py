@@ -657,7 +657,7 @@ def main():
         ex_s = mx[1] * 1e-3
         per_rank_gbs = max(sent) / ex_s / 1e9 if ex_s > 0 else 0.0
         mgpu = {
-            "pipeline": pipeline + ": histogram + all-gather + plan + partition pass | bucket exchange | local 4-pass OneSweep",
+            "pipeline": pipeline + ": histogram + all-gather + plan + partition pass | bucket exchange | local OneSweep (two-level plan or four LSD passes, as the device decides)",
             "phase_ms_max_over_ranks": {"split": mx[0], "exchange": mx[1], "local_sort": mx[2], "total": mx[3]},
             "phase_ms_rank0": {"split": rows[0][0], "exchange": rows[0][1], "local_sort": rows[0][2], "total": rows[0][3]},
             "bytes_sent_off_rank": {"max": max(sent), "min": min(sent), "sum": sum(sent)},
