@@ -433,8 +433,8 @@ def size_sweep(g, sorts=10):
     """2^10 .. 2^27 keys, keys-only and (u32, u32) pairs, `sorts` back-to-back sorts of distinct pre-generated inputs per point
     (HIP events around the batch): microseconds per sort and GKeys/s."""
     rows = {"keys": [], "pairs_u32": [], "sorts_per_point": sorts,
-            "routes": "n <= 8192: one workgroup, one launch; <= 2^20 (keys-only 2^22, u32 values 2^21): two launches (MSD pass + LDS "
-                      "bucket sorts); above: GlobalHistogram + Scan + 4 DigitBinningPass; keys-only from 3 x 2^24 keys: the two-level plan"}
+            "routes": "n <= 8192: one workgroup, one launch; <= 2^20 (keys-only 2^23, u32 values 2^22): two launches (MSD pass + LDS "
+                      "bucket sorts); above: GlobalHistogram + Scan + 4 DigitBinningPass; keys from 3 x 2^24, pairs from 2^25 + 1 elements: the two-level plan"}
     for vb, name in ((0, "keys"), (4, "pairs_u32")):
         for lg in range(10, 28):
             n = 1 << lg

@@ -533,21 +533,28 @@ void launch_mid(hipStream_t s, uint32_t tiles, uint32_t* keys, uint32_t* alt, vo
 #ifndef GS_MINIMAL
 #define GS_MID_ROW(VB, R, ...) {launch_mid<VB, 0, R, __VA_ARGS__>, launch_mid<VB, 1, R, __VA_ARGS__>, launch_mid<VB, 2, R, __VA_ARGS__>}
 #define GS_MID_NONE {nullptr, nullptr, nullptr}
-const MidLauncher g_mid[3][2][3][3] = {
+const MidLauncher g_mid[5][2][3][3] = {
     {{GS_MID_ROW(0, 0, 512, 16), GS_MID_ROW(4, 0, 512, 16), GS_MID_ROW(8, 0, 512, 16)},
      {GS_MID_ROW(0, 1, 512, 16), GS_MID_ROW(4, 1, 512, 16), GS_MID_ROW(8, 1, 512, 16)}},
     {{GS_MID_ROW(0, 0, 512, 32), GS_MID_ROW(4, 0, 512, 32), GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32), GS_MID_ROW(4, 1, 512, 32), GS_MID_NONE}},
     {{GS_MID_ROW(0, 0, 512, 32, 1024, 32), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 512, 32, 1024, 32), GS_MID_NONE, GS_MID_NONE}},
+    {{GS_MID_ROW(0, 0, 1024, 32, 1024, 34), GS_MID_NONE, GS_MID_NONE}, {GS_MID_ROW(0, 1, 1024, 32, 1024, 34), GS_MID_NONE, GS_MID_NONE}},
+    {{GS_MID_NONE, GS_MID_ROW(4, 0, 512, 32, 512, 34), GS_MID_NONE}, {GS_MID_NONE, GS_MID_ROW(4, 1, 512, 32, 512, 34), GS_MID_NONE}},
 };
 #endif
-constexpr uint32_t g_mid_tile[3] = {512 * 16, 512 * 32, 512 * 32};  // K1's tile
-constexpr uint32_t g_mid_tiles[3] = {128, 128, 256};                 // ... and how many of them at most (<= MID_MAX_TILES)
-static_assert(g_mid_tiles[2] <= gs::MID_MAX_TILES, "mid-size classes");
+// round 5: class 3 — keys-only up to 2^23 (K1: 256 tiles of 32 768, one per CU; K2 holds 34 816 keys: 6 % above the mean bucket) — and class 4 —
+// 4-byte values up to 2^22 pairs (K1: 256 tiles of 16 384; K2 holds 17 408 pairs): 74.6 -> 102 GKeys/s at 2^23 keys, profiles/r05_mid_classes.txt
+constexpr uint32_t g_mid_tile[5] = {512 * 16, 512 * 32, 512 * 32, 1024 * 32, 512 * 32};  // K1's tile
+constexpr uint32_t g_mid_tiles[5] = {128, 128, 256, 256, 256};                 // ... and how many of them at most (<= MID_MAX_TILES; never more than fit the chip at once:
+                                                                           // 512 tiles of 16 384 keys for 2^23 keys left half of them to be adopted one by one — 1.7 ms)
+static_assert(g_mid_tiles[3] <= gs::MID_MAX_TILES && g_mid_tiles[4] <= gs::MID_MAX_TILES, "mid-size classes");
 // class of a mid-size sort, -1: the general pipeline
 inline int mid_class(uint32_t n, uint32_t vb) {
     if (n <= g_mid_tiles[0] * g_mid_tile[0]) return 0;
     if (n <= g_mid_tiles[1] * g_mid_tile[1] && vb != 8) return 1;
     if (n <= g_mid_tiles[2] * g_mid_tile[2] && vb == 0) return 2;
+    if (n <= g_mid_tiles[3] * g_mid_tile[3] && vb == 0) return 3;
+    if (n <= g_mid_tiles[4] * g_mid_tile[4] && vb == 4) return 4;
     return -1;
 }
 
@@ -555,8 +562,8 @@ inline int mid_class(uint32_t n, uint32_t vb) {
 // keys only) run before the stream waits for it; the one- and two-launch routes wait first.
 gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
                     gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb, hipEvent_t values_ready = nullptr) {
-    // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20 (2^21 for keys-only and
-    // 4-byte values, 2^22 for keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
+    // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20 (2^22 pairs with 4-byte
+    // values, 2^23 keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
     // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
     const int mid_cls = (h->mid_path && h->shape_auto && n > gs::SMALL_TILE && !is_key64(kt)) ? mid_class(n, vb) : -1;
 #ifdef GS_MINIMAL

@@ -41,6 +41,9 @@ namespace gs {
 //   K2 512 x 16 =  8 192 keys  n <= 2^20   every value width                                      K1 <= 128 tiles of  8 192
 //   K2 512 x 32 = 16 384 keys  n <= 2^21   keys-only and 4-byte values (stage 64 + 64 KiB)        K1 <= 128 tiles of 16 384
 //   K2 1024 x 32 = 32 768 keys n <= 2^22   keys-only (stage 128 KiB)                              K1 <= 256 tiles of 16 384
+//   K2 1024 x 34 = 34 816 keys n <= 2^23   keys-only (stage 136 KiB: what 160 KiB of LDS hold)    K1 <= 256 tiles of 32 768 (one per CU)
+//   K2 512 x 34  = 17 408 pairs n <= 2^22  4-byte values (stage 68 + 68 KiB)                      K1 <= 256 tiles of 16 384
+//      (round 5: a top-byte bucket of 2^23 uniform keys is 32 768 +- 181 keys — 6 % of slack; anything less even runs K1's LSD route)
 constexpr uint32_t MID_THREADS = 512, MID_KPT = 16, MID_TILE = MID_THREADS * MID_KPT;  // the smallest shape
 constexpr uint32_t MID_MAX_TILES = 256;                                                // (the smallest shape stops at 128: one launch wave of half the CUs)
 constexpr uint32_t MID_MAX_KEYS = 128 * MID_TILE;                                      // 2^20: limit of the smallest shape

@@ -164,7 +164,7 @@ class OneSweep:
         check(self._lib.gs_onesweep_set_small_path(self._h, 1 if on else 0), "gs_onesweep_set_small_path")
 
     def set_mid_path(self, on: bool) -> None:
-        """Two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (keys-only: 2^22, 4-byte values: 2^21; default on)."""
+        """Two-launch MSD + bucket sort for single-tile limit < n <= 2^20 (keys-only: 2^23, 4-byte values: 2^22; default on)."""
         check(self._lib.gs_onesweep_set_mid_path(self._h, 1 if on else 0), "gs_onesweep_set_mid_path")
 
     def set_skip_passes(self, on: bool) -> None:

@@ -163,11 +163,11 @@ int gs_onesweep_get_rank_mode(gs_onesweep* h); /* the mode in use (after the cre
  * mode, n <= 16384 for keys-only and 4-byte values, n <= 32768 for keys-only — unless this is switched off
  * (tests use 0 to push small sizes through the tiled path as well). */
 gs_status gs_onesweep_set_small_path(gs_onesweep* h, int on);
-/* Mid sizes (single-tile limit < n <= 2^20; keys-only and 4-byte values up to 2^21, keys-only up to 2^22; 32-bit keys) are
+/* Mid sizes (single-tile limit < n <= 2^20; 4-byte values up to 2^22 pairs, keys-only up to 2^23; 32-bit keys) are
  * sorted in TWO launches instead of seven: one MSD pass on the
  * top byte (its workgroups claim their tiles and adopt the tiles of workgroups that were never dispatched: no residency
  * requirement) and one workgroup per top-byte bucket that sorts the remaining 24
- * bits in LDS; a top byte too skewed for that (a bucket above one tile: 8192 / 16 384 / 32 768 keys) is noticed on the device and the first kernel
+ * bits in LDS; a top byte too skewed for that (a bucket above what the class's workgroup holds: 8192 … 34 816 keys) is noticed on the device and the first kernel
  * runs the four LSD passes itself (reference size sweep GPUSortingD3D12/Tests.h:392-393,415-416).  Same
  * result either way; 0 sends these sizes through the general path.  Only used while the library picks the tile shape.
  * Default 1 (gs_onesweep_options::mid_path at create). */

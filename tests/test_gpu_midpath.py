@@ -101,6 +101,47 @@ def test_mid_path_larger_tile_classes(gpu, oracle, routing, vb, kind):
         s.close()
 
 
+@pytest.mark.parametrize("kind", ["uniform", "preset4", "top-constant", "slightly-uneven"])
+def test_mid_path_2pow23_class(gpu, oracle, kind):
+    """Round 5: keys-only up to 2^23 keys in two launches — 512 tiles of 16 384 keys in the MSD kernel, buckets of 32 768 +- 181 keys in
+    workgroups that hold 34 816 (1024 x 34: what 160 KiB of LDS hold).  A top byte that is only slightly uneven (one bucket 10 % above the
+    mean) does not fit and takes the LSD route inside the first kernel; both must be exact, as must the general pipeline."""
+    rng = np.random.default_rng(41)
+    for n in ((1 << 22) + 1, 6000001, (1 << 23) - 5, 1 << 23):
+        if kind == "slightly-uneven":
+            keys = oracle.init_random(n, n + 4, 0)
+            move = (keys >> np.uint32(24) == 200) & (rng.integers(0, 10, size=n) < 5)   # half of bucket 200 moves into bucket 17
+            keys = np.where(move, (keys & np.uint32(0x00FFFFFF)) | np.uint32(17 << 24), keys).astype(np.uint32)
+        else:
+            keys = _keys(oracle, rng, n, kind)
+        want = oracle.std_sort(keys, 0, 0)
+        s = gpu.OneSweep(n)
+        for mid in (True, False, True):
+            s.set_mid_path(mid)
+            ok, _ = _sort(gpu, s, keys, None)
+            np.testing.assert_array_equal(ok, want, err_msg=f"{kind} n={n} mid={mid}")
+        s.close()
+    for kt, order in ((1, 1), (2, 0)):
+        n = (1 << 23) - 77
+        keys = _keys(oracle, rng, n, "uniform")
+        s = gpu.OneSweep(n, order, kt)
+        ok, _ = _sort(gpu, s, keys, None)
+        np.testing.assert_array_equal(ok, oracle.std_sort(keys, kt, order), err_msg=f"kt={kt} order={order}")
+        s.close()
+    # the same step for 4-byte values: up to 2^22 pairs in two launches (buckets of 16 384 +- 128 pairs in workgroups that hold 17 408)
+    for n, order in (((1 << 21) + 3, 0), (3500001, 1), (1 << 22, 0)):
+        keys = _keys(oracle, rng, n, kind) if kind != "slightly-uneven" else oracle.init_random(n, n + 4, 1)
+        vals = np.arange(n, dtype=np.uint32)
+        wk, wv = oracle.std_sort(keys, 0, order, vals)
+        s = gpu.OneSweep(n, order, 0, gpu.MODE_PAIRS, 4)
+        for mid in (True, False):
+            s.set_mid_path(mid)
+            ok, ov = _sort(gpu, s, keys, vals)
+            np.testing.assert_array_equal(ok, wk, err_msg=f"pairs {kind} n={n} mid={mid}")
+            np.testing.assert_array_equal(ov, wv, err_msg=f"pairs values {kind} n={n} mid={mid}")
+        s.close()
+
+
 @pytest.mark.parametrize("kt,order,rank", [(1, 1, 1), (2, 0, 0), (2, 1, 1), (0, 1, 0)])
 def test_mid_path_larger_tile_classes_types(gpu, oracle, routing, kt, order, rank):
     rng = np.random.default_rng(31)
