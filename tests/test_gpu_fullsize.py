@@ -318,3 +318,29 @@ def test_3x2pow27_two_level_plan_against_the_lsd_passes(gpu, vb):
     assert bool((out[0][0] == out[1][0]).all().item()), "keys differ between the plans"
     if vb:
         assert bool((out[0][1] == out[1][1]).all().item()), "values differ between the plans"
+
+
+@pytest.mark.parametrize("n,vb", [(3 << 24, 0), ((3 << 24) - 1, 0), (1 << 27, 0), ((1 << 27) + 1, 0), ((1 << 28) + 1, 0), ((1 << 25) + 1, 4), (1 << 27, 8),
+                                  ((1 << 27) + 1, 4)])
+def test_two_level_plan_at_its_thresholds_and_class_borders(gpu, n, vb):
+    """The sizes at which the default routing changes: the plan's thresholds (keys 3 x 2^24, pairs 2^25 + 1) and the borders of the
+    bucket-local sort's size classes (2^27 | 2^27 + 1, 2^28 | 2^28 + 1).  Default routing against the LSD passes (plan 1), element for
+    element, values = original index."""
+    import torch
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    gpu.init_random(dk, 4000 + (n & 0xFFFF), 0)   # (seed 0 would be the generator's degenerate state: every draw of a lane equal)
+    out = []
+    for plan in (1, 0):
+        s = gpu.OneSweep(n, mode=gpu.MODE_PAIRS if vb else gpu.MODE_KEYS_ONLY, value_bytes=vb, plan=plan)
+        k = dk.clone()
+        v = torch.arange(n, dtype=torch.int32 if vb == 4 else torch.int64, device="cuda") if vb else None
+        s.sort(k, v)
+        s.check()
+        offered = n >= ((1 << 25) + 1 if vb else 3 << 24)
+        assert s.last_plan()["two_level"] == (plan == 0 and offered), (n, vb, plan, s.last_plan())
+        out.append((k, v))
+        s.close()
+    assert gpu.validate(out[1][0]) == 0
+    assert bool((out[0][0] == out[1][0]).all().item())
+    if vb:
+        assert bool((out[0][1] == out[1][1]).all().item())

@@ -227,3 +227,39 @@ def test_two_level_plan_default_threshold_and_2pow27(gpu, oracle):
     ref = oracle.std_sort_parallel(keys, oracle.hardware_threads())
     assert bool((dk == torch.from_numpy(ref.view(np.int32)).cuda()).all().item())
     s.close()
+
+
+@pytest.mark.parametrize("vb", [4, 8])
+def test_two_level_plan_pairs_in_a_hip_graph(gpu, oracle, pair_sorters, vb):
+    """Pairs: captured once, replayed on uniform keys (two-level plan) and on skewed keys (LSD passes on position chains) — the same
+    captured launches, value = index exact both times."""
+    import torch
+    n = (1 << 21) + 4097
+    s = pair_sorters(vb, 0, 0)
+    s.set_plan(2)
+    vdt = torch.int32 if vb == 4 else torch.int64
+    dk = torch.empty(n, dtype=torch.int32, device="cuda")
+    dv = torch.arange(n, dtype=vdt, device="cuda")
+    alt, valt = torch.empty_like(dk), torch.empty_like(dv)
+    gpu.init_random(dk, 5, 0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s.sort(dk, dv, alt_keys=alt, alt_values=valt)  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s.sort(dk, dv, alt_keys=alt, alt_values=valt)
+    for seed, andc, two_level in ((6, 0, True), (7, 3, False), (8, 0, True)):
+        gpu.init_random(dk, seed, andc)
+        dv.copy_(torch.arange(n, dtype=vdt, device="cuda"))
+        torch.cuda.synchronize()
+        k = dk.cpu().numpy().view(np.uint32)
+        perm = np.argsort(k, kind="stable")
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), k[perm])
+        np.testing.assert_array_equal(dv.cpu().numpy().astype(np.int64), perm)
+        assert s.last_plan()["two_level"] == two_level
+    s.check()
