@@ -263,3 +263,72 @@ def test_two_level_plan_pairs_in_a_hip_graph(gpu, oracle, pair_sorters, vb):
         np.testing.assert_array_equal(dv.cpu().numpy().astype(np.int64), perm)
         assert s.last_plan()["two_level"] == two_level
     s.check()
+
+
+@pytest.mark.parametrize("heavy,two_level", [(3071, True), (3072, True), (3073, False), (40000, False)])
+def test_two_level_plan_bucket_capacity_boundary(gpu, heavy, two_level):
+    """The device's decision is exact: a 16-bit prefix holding exactly what the bucket-local sort's workgroup holds (3072 keys in the size
+    class up to 2^27 keys) still runs the two-level plan; one key more and the same launches run the LSD passes.  Both results exact."""
+    import torch
+    n = (1 << 22) + 999
+    g = torch.Generator(device="cuda"); g.manual_seed(heavy)
+    k = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device="cuda", generator=g) & 0xFFFFFFFF
+    k = torch.where((k >> 16) == 0x1234, k ^ 0x00010000, k)                # nobody has prefix 0x1234 ...
+    pos = torch.randperm(n, device="cuda", generator=g)[:heavy]
+    k[pos] = (k[pos] & 0xFFFF) | (0x1234 << 16)                              # ... but exactly `heavy` keys
+    want = torch.sort(k).values
+    for order in (0, 1):
+        s = gpu.OneSweep(n, order, small_path=0, mid_path=0, plan=2, position_chains_min_log2=20)
+        dk = k.to(torch.int32)
+        s.sort(dk)
+        s.check()
+        lp = s.last_plan()
+        got = dk.to(torch.int64) & 0xFFFFFFFF
+        assert bool(torch.equal(got, want if order == 0 else torch.flip(want, dims=(0,)))), (heavy, order)
+        assert lp["two_level"] == two_level and (not two_level or lp["largest_bucket"] == max(heavy, lp["largest_bucket"])), (heavy, lp)
+        s.close()
+
+
+def test_two_level_plan_fuzz(gpu):
+    """A seeded sweep of sizes and key shapes through the forced two-level plan — masks that empty most prefixes or most low bits, constant
+    top bytes, mixtures of a narrow and a wide range, runs of equal keys — keys-only and (u32, u32) pairs with value = index, both orders,
+    against torch's stable sort.  Whatever the device decides (two-level plan or its fall-back), the result must be exact."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(20260926)
+    rng = np.random.default_rng(505)
+    ran = {True: 0, False: 0}
+    for it in range(40):
+        n = int(rng.integers(1 << 20, 1 << 23)) | 1
+        k = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device="cuda", generator=g) & 0xFFFFFFFF
+        shape = it % 8
+        if shape == 1:
+            k &= int(rng.integers(0, 1 << 32)) | 0xFFFF0000                  # random low-bit mask: duplicates inside the buckets
+        elif shape == 2:
+            k &= 0x0FFFFFFF | (int(rng.integers(0, 16)) << 28)               # few top nibbles
+        elif shape == 3:
+            k = (k & 0x00FFFFFF) | (int(rng.integers(0, 256)) << 24)         # constant top byte: 256 prefixes hold everything
+        elif shape == 4:
+            narrow = torch.rand(n, device="cuda", generator=g) < 0.3
+            k = torch.where(narrow, (k & 0xFFFFF) | 0x7A500000, k)            # 30 % of the keys inside sixteen prefixes
+        elif shape == 5:
+            k = (k >> 7) << 7                                                 # runs of up to 128 equal keys after sorting
+        elif shape == 6:
+            k = torch.sort(k).values                                          # presorted
+        elif shape == 7:
+            k &= 0xFFFF00FF                                                   # byte 1 constant: an identity pass inside every bucket
+        pairs = it % 3 == 0
+        order = (it // 3) % 2
+        s = gpu.OneSweep(n, order, 0, gpu.MODE_PAIRS if pairs else gpu.MODE_KEYS_ONLY, 4 if pairs else 0, small_path=0, mid_path=0, plan=2,
+                         position_chains_min_log2=20)
+        dk = k.to(torch.int32)
+        dv = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+        ref = torch.sort(k, stable=True)
+        s.sort(dk, dv)
+        s.check()
+        ran[s.last_plan()["two_level"]] += 1
+        wk, wi = (ref.values, ref.indices) if order == 0 else (torch.flip(ref.values, dims=(0,)), torch.flip(ref.indices, dims=(0,)))
+        assert bool(torch.equal(dk.to(torch.int64) & 0xFFFFFFFF, wk)), (it, n, shape, pairs, order)
+        if pairs:
+            assert bool(torch.equal(dv.to(torch.int64), wi)), (it, n, shape, pairs, order, "values")
+        s.close()
+    assert ran[True] >= 10 and ran[False] >= 5, ran   # both outcomes were exercised
