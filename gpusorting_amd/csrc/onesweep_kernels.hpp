@@ -29,8 +29,10 @@
 //     (identity passes are dropped in pairs, a skewed pass ranks with wave-aggregated adds, a skewed SORT runs every pass on
 //     position chains whose bases the pass before counts while it scatters), and a look-back that waits too long
 //     recounts the missing tile itself, so no workgroup depends on another's progress for more than a bounded time.
-//   * a sort is 7 launches: GlobalHistogram (which also clears the scan state), the sum of its workgroups' tables, Scan,
-//     4 x DigitBinningPass.  (ls_kernels.hpp holds a second plan for large keys-only sorts, opt-in.)
+//   * a sort on the LSD plan is 7 launches: GlobalHistogram (which also clears the scan state), the sum of its workgroups' tables,
+//     Scan, 4 x DigitBinningPass.  Large sorts are offered the TWO-LEVEL plan (hybrid_kernels.hpp: the same DigitBinningPass on bytes
+//     3 and 2 — told its digit and chain count by the info block — then bucket-local LDS sorts of the low 16 bits: 28 B/key instead of
+//     36), chosen per sort on the device.  (ls_kernels.hpp: round 4's local-sort-first plan, tuning build only.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
