@@ -104,27 +104,36 @@ def kernel_sources_sha256() -> str:
     return h.hexdigest()[:16]
 
 
+def pmc_traffic_file():
+    """The newest profiles/rNN_pmc_traffic.json (tools/make_pmc_json.py writes one per round)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
 def pmc_traffic(log2_keys, vb, entropy, shape, tile_keys, kernel="pass"):
     """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate rocprofv3 --pmc
     passes of this same command and committed under profiles/) — a BORROWED number: measured by the builder's rocprofv3 runs, not
-    by this run.  It is only handed on if it was measured on THIS build: profiles/r05_pmc_traffic.json carries the hash of the kernel
-    sources it was collected with (the GPU box has no .git, so a commit id could not be checked there); any other source state
-    returns (None, reason).  Returns (bytes or None, provenance dict)."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, {"reason": "profiles/r05_pmc_traffic.json is missing"}
+    by this run.  The file carries the hash of the kernel sources it was collected with (the GPU box has no .git, so a commit id
+    could not be checked there); provenance["sources_match"] says whether this tree still hashes to it — a number from another source
+    state is handed on as well, flagged stale (round 5 dropped it instead and the driver's record then had no traffic at all).
+    Returns (bytes or None, provenance dict)."""
+    path = pmc_traffic_file()
+    if path is None:
+        return None, {"reason": "no profiles/rNN_pmc_traffic.json"}
+    rel = os.path.relpath(path, ROOT)
     if log2_keys != 28 or entropy or shape:
         return None, {"reason": "the committed counters are for 2^28 keys, entropy preset 1, the library's own tile shapes"}
     d = json.load(open(path))
     now = kernel_sources_sha256()
-    if d.get("kernel_sources_sha256") != now:
-        return None, {"reason": f"the committed counters were collected on kernel sources {d.get('kernel_sources_sha256')}, this tree is {now}: not carried over"}
     e = d.get("keys" if not vb else f"pairs{vb}", {}).get(kernel)
     if not e:
         return None, {"reason": f"no counters committed for value bytes {vb} / {kernel}"}
-    return e["traffic_bytes_per_launch"], {"source": f"profiles/r05_pmc_traffic.json ({d.get('collected_by')}; commit {d.get('commit')}, kernel sources {now}); "
-                                                     "builder-run rocprofv3 --pmc passes of the same command, NOT measured by this run",
-                                           "kernel": e.get("kernel"), "fetch_bytes": e.get("fetch_bytes"), "write_bytes": e.get("write_bytes")}
+    match = d.get("kernel_sources_sha256") == now
+    return e["traffic_bytes_per_launch"], {
+        "source": f"{rel} ({d.get('collected_by')}; commit {d.get('commit')}); builder-run rocprofv3 --pmc passes of the same command, NOT measured by this run",
+        "sources_match": match, "measured_on_kernel_sources": d.get("kernel_sources_sha256"), "this_tree": now,
+        "kernel": e.get("kernel"), "fetch_bytes": e.get("fetch_bytes"), "write_bytes": e.get("write_bytes"), "ratio_to_algorithmic": e.get("ratio")}
 
 
 def box_floor(n):
@@ -493,6 +502,97 @@ def size_sweep(g, sorts=10):
     return rows
 
 
+HEADLINE_MAX_BYTES = 4096  # the driver keeps a bounded tail of stdout: round 5's 28 KB line was cut and recorded as unparsed
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def headline_line(out: dict) -> str:
+    """The ONE JSON line the driver parses, from the full record: the contract's fields, `roofline` (dominant kernel, with the counter
+    traffic) and `cpu_baseline`, plus a numbers-only digest of the `more` block — <= HEADLINE_MAX_BYTES, printed LAST.  Everything else
+    (per-kernel tables, box floor, entropy / size sweeps, the rocPRIM comparator) goes to gpurun_out/bench_full.json and to '# bench_full'
+    lines printed BEFORE this one."""
+    rf = out["roofline"]
+    ws = rf.get("whole_sort", {})
+    prov = rf.get("traffic_provenance") or {}
+    roof = {
+        "bound": rf["bound"], "kernel": rf["kernel"].split(" (")[0], "achieved": _r(rf["achieved"], 1), "peak": rf["peak"], "unit": rf["unit"],
+        "frac": _r(rf["frac"]), "traffic": rf.get("traffic"),
+        "traffic_src": (f"{prov['source'].split(' (')[0]}, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, sources_match={prov.get('sources_match')}"
+                        if "source" in prov else prov.get("reason")),
+        "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "avg_launch_ms": _r(rf["avg_launch_ms"]),
+        "launches_averaged": rf["launches_averaged"], "plan": rf["plan"].split(":")[0],
+        "per_kernel_ms": {k: _r(v) for k, v in rf["per_kernel_ms"].items()},
+        "whole_sort": {"bytes_per_key_metric": ws.get("bytes_per_key"), "frac_of_8000": _r(ws.get("frac_of_8000")),
+                       "bytes_per_key_moved": ws.get("bytes_per_key_moved_by_this_plan"), "moved_frac_of_8000": _r(ws.get("moved_frac_of_8000"))},
+    }
+    if "frac_of_box_floor" in rf:
+        roof["frac_of_box_tile_copy"] = _r(rf["frac_of_box_floor"]["pass"])
+    cfg = out["config"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "keys_per_gpu", "entropy_preset", "generator", "tile_keys", "verified_sorted") if k in cfg}
+    line["roofline"] = roof
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {
+        "value": _r(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+        "single_thread_std_sort": _r(cb.get("single_thread_std_sort", {}).get("value"), 5)}
+    mg = out.get("multi_gpu")
+    if mg:
+        line["multi_gpu"] = {"phase_ms_max_over_ranks": {k: _r(v) for k, v in mg["phase_ms_max_over_ranks"].items()},
+                             "exchange_GBps_per_link": _r(mg["exchange_GBps_per_link"], 1), "frac_of_link_peak": _r(mg["frac_of_link_peak"]),
+                             "pipeline": mg["pipeline"].split(":")[0][:80]}
+    more = out.get("more")
+    if more:
+        dg = {}
+        for k in ("pairs_u32", "pairs_u64", "keys64"):
+            if k in more and "value" in more[k]:
+                dg[k] = _r(more[k]["value"], 1)
+        for k, rows in more.get("entropy_sweep", {}).items():
+            dg["entropy_" + k] = [_r(r["value"], 1) for r in rows]
+        if "other_inputs" in more:
+            dg["other_inputs"] = {r["input"]: _r(r["value"], 1) for r in more["other_inputs"]}
+        sw = more.get("size_sweep", {})
+        for k in ("keys", "pairs_u32"):
+            if k in sw:
+                dg["size_sweep_" + k + "_log2_20_27"] = [_r(r["GKeys_per_s"], 1) for r in sw[k] if 20 <= r["log2_keys"] <= 27]
+        rows = (more.get("comparator") or {}).get("rows") or []
+        big = [r for r in rows if r.get("log2_keys") == 28 and r.get("entropy_preset") == 1]
+        if big:
+            dg["rocprim_2pow28"] = {r["mode"]: [_r(r["rocprim_GKeys_per_s"], 1), _r(r["gpusort_GKeys_per_s"], 1)] for r in big}
+        dg["unit"] = "GKeys/s; measured after the timed region, never part of value"
+        line["more_digest"] = dg
+    line["full_record"] = out.get("full_record", "stdout lines starting '# bench_full' above this one")
+    text = json.dumps(line)
+    if len(text) > HEADLINE_MAX_BYTES:  # never let diagnostics take the record with them
+        line.pop("more_digest", None)
+        roof.pop("per_kernel_ms", None)
+        text = json.dumps(line)
+    return text
+
+
+def emit(out: dict) -> None:
+    """Full record -> gpurun_out/bench_full.json + '# bench_full <block> <json>' lines; then the compact line, LAST."""
+    path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+        out["full_record"] = "gpurun_out/bench_full.json; stdout lines starting '# bench_full' above"
+    except OSError:
+        pass
+    for block in ("roofline", "box_floor", "multi_gpu", "cpu_baseline"):
+        if out.get(block) is not None:
+            print(f"# bench_full {block} " + json.dumps(out[block]))
+    for k, v in (out.get("more") or {}).items():
+        print(f"# bench_full more.{k} " + json.dumps(v))
+    sys.stdout.flush()
+    print(headline_line(out))
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -748,7 +848,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_log2)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
     if not (sorted_ok and total_ok):

@@ -201,3 +201,39 @@ def test_msd_plan_device_kernel_equals_host(gpu):
             assert lib.gs_msd_plan(p(t), nbins, world, rank, cap, p(host)) == 0
             assert lib.gs_debug_msd_plan_device(p(t), nbins, world, rank, cap, p(dev), None) == 0
             np.testing.assert_array_equal(dev, host, err_msg=f"world={world} nbins={nbins} rank={rank}")
+
+
+def test_bench_headline_line_is_small_and_complete():
+    """bench.py's LAST stdout line is what the driver parses (contract: one JSON line with `roofline` and `cpu_baseline`); round 5's
+    28 KB line outgrew the driver's stdout tail and was recorded as unparsed.  The formatter is run on a canned full record (a real
+    round-5 run, tests/golden/bench_full_record_r05.json): the line stays under 4 KiB whatever the `more` block holds, parses, and
+    carries every field the contract names."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_record_r05.json")))
+    full["roofline"]["traffic"] = 2219491840   # (that run's line had no counters attached; the formatter must carry them when present)
+    full["roofline"]["traffic_provenance"] = {"source": "profiles/r05_pmc_traffic.json (x; commit y)", "sources_match": True}
+    line = bench.headline_line(full)
+    assert "\n" not in line and len(line) <= bench.HEADLINE_MAX_BYTES < 6000
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"]
+    assert d["config"]["workload"].startswith("2^28 uniform-random uint32 keys-only OneSweep")
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"] == 2219491840
+    assert rf["algorithmic_bytes_per_launch"] == 8 << 28 and rf["avg_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+    assert len(d["more_digest"]["entropy_pairs_u64"]) == 5
+    # a record whose digest would not fit loses the digest, never the contract's fields
+    full["more"]["entropy_sweep"]["keys"] = full["more"]["entropy_sweep"]["keys"] * 400
+    d2 = json.loads(bench.headline_line(full))
+    assert "more_digest" not in d2 and d2["roofline"]["frac"] == rf["frac"] and d2["cpu_baseline"]["value"] == cb["value"]
+    # the counters file the line borrows `traffic` from exists and names the sources it was measured on
+    path = bench.pmc_traffic_file()
+    assert path and "kernel_sources_sha256" in json.load(open(path))

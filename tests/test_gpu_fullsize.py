@@ -127,12 +127,15 @@ def test_2pow28_low_entropy_properties(gpu, andc, pairs):
 
 
 # ---- bit-exact at the headline size ------------------------------------------------------------
-def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0, plan=None):
-    """Sort 2^log2n generator keys (seed = log2n as the reference's big sizes, OneSweepDispatcher.cuh:116-128)
+def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0, plan=None, n=None, two_level=None):
+    """Sort n = 2^log2n (or `n`) generator keys (seed = log2n as the reference's big sizes, OneSweepDispatcher.cuh:116-128)
     with value = original index and compare keys AND values element for element with the oracle's stable
-    order.  The comparison itself runs on the GPU (a gather and two equality reductions: plumbing)."""
+    order (descending: its exact reverse, SortCommon.hlsl:594-597,645-656; typed keys: :134-154).  Keys-only sorts of typed or
+    descending keys are compared through the oracle's permutation as well.  The comparison itself runs on the GPU (a gather and
+    two equality reductions: plumbing).  two_level: what gs_onesweep_last_plan must report for the sort."""
     import torch
-    n = 1 << log2n
+    if n is None:
+        n = 1 << log2n
     dk = torch.empty(n, dtype=torch.int32, device="cuda")
     gpu.init_random(dk, log2n + 100 * andc, andc)
     torch.cuda.synchronize()
@@ -148,21 +151,59 @@ def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0, pla
         s.set_plan(plan)
     s.sort(dk, dv)
     s.check()
-    if vb:
+    if two_level is not None:
+        assert s.last_plan()["two_level"] == two_level, s.last_plan()
+    if vb or kt or order:
         perm = oracle.sort_permutation_parallel(keys, kt, order)          # stable order by key (desc: its reverse)
         dperm = torch.from_numpy(perm.view(np.int32)).cuda()
-        assert bool((dv.to(torch.int32) == dperm).all().item()), "payload order differs from the stable sort"
-        if vb == 8:
-            assert bool((dv >> 32 == 0).all().item())
+        if vb:
+            assert bool((dv.to(torch.int32) == dperm).all().item()), "payload order differs from the stable sort"
+            if vb == 8:
+                assert bool((dv >> 32 == 0).all().item())
         idx = dperm.to(torch.int64) & 0xFFFFFFFF
         del dperm
         expect = orig[idx]
         assert bool((dk == expect).all().item()), "sorted keys differ from the oracle"
     else:
-        assert kt == 0 and order == 0
         ref = oracle.std_sort_parallel(keys, oracle.hardware_threads())
         assert bool((dk == torch.from_numpy(ref.view(np.int32)).cuda()).all().item()), "sorted keys differ from the oracle"
     s.close()
+
+
+# ---- typed keys / descending order on the two-level plan at the sizes the DEFAULT routing uses it ----
+# The plan's descending rule: pass B writes mirrored, the bucket-local sort reads and writes mirrored (hybrid_kernels.hpp); its key
+# transforms run at every load / store as in the LSD passes.  Bucket-sort classes by n: <= 2^27 (256 x 12), <= 2^28 (512 x 12),
+# <= 2^29 (1024 x 12), above (1024 x 24).  Reference rule: GPUSortingD3D12/Shaders/SortCommon.hlsl:134-154,594-597,645-656; its
+# test matrix: GPUSortingD3D12/Tests.h:6-186.
+@pytest.mark.parametrize("n,kt,order,vb", [
+    ((1 << 27) + 1, 1, 1, 0),   # class 1 at its lower border: int32 keys, descending
+    (1 << 28, 2, 1, 0),         # class 1, the headline size: float keys, descending
+    (1 << 28, 0, 1, 4),         # class 1: (u32, u32) pairs descending, value = index
+    (1 << 27, 1, 1, 8),         # class 0 at its upper border: (i32, u64) pairs descending, value = index
+    (3 << 27, 0, 1, 0),         # class 2: descending
+    (3 << 27, 2, 0, 4),         # class 2: float keys with u32 values, ascending
+    ((1 << 28) + 12345, 1, 0, 8),  # class 2 at its lower border, ragged: (i32, u64) pairs ascending
+])
+def test_two_level_plan_typed_and_descending_exact_default_routing(gpu, oracle, n, kt, order, vb):
+    _exact_case(gpu, oracle, 28 + kt + 2 * order, 0, vb, order=order, kt=kt, n=n, two_level=True)
+
+
+def test_maximum_size_2pow30_minus_1_exact_vs_oracle(gpu, oracle):
+    """The two-level plan's largest class (n > 2^29: 1024 x 24 = 24 576-key buckets) at the largest n the API accepts, EXACT against
+    the oracle's sort (test_maximum_size_2pow30_minus_1 holds properties only)."""
+    _exact_case(gpu, oracle, 30, 0, 0, n=(1 << 30) - 1, two_level=True)
+
+
+def test_2pow30_minus_1_descending_int_keys_exact_vs_oracle(gpu, oracle):
+    """... and the same class mirrored: int32 keys, descending."""
+    _exact_case(gpu, oracle, 31, 0, 0, order=1, kt=1, n=(1 << 30) - 1, two_level=True)
+
+
+def test_2pow28_ballot_ranking_takes_the_lsd_plan_exact(gpu, oracle):
+    """rank_mode 0 (the ballot multi-split: what a part that fails gs_selftest_lds_atomic_order runs) at the headline
+    size: the two-level plan, position chains and the pairs' bucket sort exist for LDS-atomic ranking only, so the sort must take the
+    four LSD passes — and stay exact."""
+    _exact_case(gpu, oracle, 28, 0, 0, rank_mode=0, two_level=False)
 
 
 @pytest.mark.parametrize("andc", [0, 1, 2, 3, 4])
