@@ -3,7 +3,7 @@ HIPCC ?= hipcc
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC
 LIB := gpusorting_amd/lib/libgpusort.so
 SRC := gpusorting_amd/csrc/gpusort_capi.hip
-HDR := gpusorting_amd/csrc/onesweep_kernels.hpp gpusorting_amd/csrc/onesweep_ablation.hpp gpusorting_amd/csrc/mid_kernels.hpp gpusorting_amd/csrc/hybrid_kernels.hpp gpusorting_amd/csrc/ls_kernels.hpp gpusorting_amd/csrc/msd_kernels.hpp gpusorting_amd/csrc/gpusort_mgpu.hpp include/gpusort.h
+HDR := gpusorting_amd/csrc/onesweep_kernels.hpp gpusorting_amd/csrc/onesweep_ablation.hpp gpusorting_amd/csrc/mid_kernels.hpp gpusorting_amd/csrc/hybrid_kernels.hpp gpusorting_amd/csrc/msd_kernels.hpp gpusorting_amd/csrc/gpusort_mgpu.hpp include/gpusort.h
 
 all: $(LIB) gpusorting_amd/lib/libgpusort_fault.so gpusorting_amd/lib/libgpusort_fault_nofallback.so gpusorting_amd/lib/libgpusort_tuning.so oracle tools
 $(LIB): $(SRC) $(HDR)

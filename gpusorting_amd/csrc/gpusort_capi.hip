@@ -15,9 +15,6 @@
 #include "onesweep_kernels.hpp"
 #include "mid_kernels.hpp"
 #include "hybrid_kernels.hpp"
-#ifdef GS_TUNING  // the round-4 local-sort plan: an experiment kept in the tuning build only (slower than the default)
-#include "ls_kernels.hpp"
-#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -189,39 +186,6 @@ constexpr int MID_SHAPE = 2;         // g_shapes index used for n <= mid_keys(vb
 // workgroup per CU), up to 2^23 with 4-byte values (1024 x 16 wins from 2^24)
 inline uint32_t mid_keys(uint32_t vb) { return vb == 4 ? (1u << 23) : (1u << 25); }
 
-#ifdef GS_TUNING
-// ---- local-sort plan (ls_kernels.hpp): four launches, no histogram sweep ----
-using LsFirstLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, uint32_t* runs_t, uint32_t* slices, uint32_t* slab,
-                                 size_t zero_end, uint32_t n, uint32_t plan);
-using LsPassLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t*, uint32_t*, const uint32_t* runs, const uint32_t* eprefix, const uint32_t* stab,
-                                uint32_t nt_pad, uint32_t* slab, uint32_t* slices, uint32_t desc_off, uint32_t n, uint32_t pass, uint32_t mode);
-template <int KT>
-void launch_ls_first(hipStream_t s, uint32_t grid, const uint32_t* in, uint32_t* out, uint32_t* runs_t, uint32_t* slices, uint32_t* slab,
-                     size_t zero_end, uint32_t n, uint32_t plan) {
-    hipLaunchKernelGGL((gs::ls_first_kernel<KT>), dim3(grid), dim3(gs::LS_THREADS), 0, s, in, out, runs_t, slices, slab, zero_end, n, plan);
-}
-template <int KT, bool GATHER, bool COUNT>
-void launch_ls_pass(hipStream_t s, uint32_t grid, const uint32_t* in, uint32_t* out, const uint32_t* runs, const uint32_t* eprefix, const uint32_t* stab,
-                    uint32_t nt_pad, uint32_t* slab, uint32_t* slices, uint32_t desc_off, uint32_t n, uint32_t pass, uint32_t mode) {
-    hipLaunchKernelGGL((gs::ls_pass_kernel<KT, GATHER, COUNT>), dim3(grid), dim3(gs::LS_THREADS), 0, s, in, out, runs, eprefix, stab, nt_pad, slab, slices,
-                       desc_off, n, pass, mode);
-}
-#ifdef GS_MINIMAL
-const LsFirstLauncher g_ls_first[3] = {launch_ls_first<0>, nullptr, nullptr};
-const LsPassLauncher g_ls_pass[3][3] = {{launch_ls_pass<0, true, true>, nullptr, nullptr}, {launch_ls_pass<0, false, true>, nullptr, nullptr}, {launch_ls_pass<0, false, false>, nullptr, nullptr}};
-#else
-const LsFirstLauncher g_ls_first[3] = {launch_ls_first<0>, launch_ls_first<1>, launch_ls_first<2>};
-// [gather / middle / last][key type]
-const LsPassLauncher g_ls_pass[3][3] = {{launch_ls_pass<0, true, true>, launch_ls_pass<1, true, true>, launch_ls_pass<2, true, true>},
-                                        {launch_ls_pass<0, false, true>, launch_ls_pass<1, false, true>, launch_ls_pass<2, false, true>},
-                                        {launch_ls_pass<0, false, false>, launch_ls_pass<1, false, false>, launch_ls_pass<2, false, false>}};
-#endif
-// row stride of R and E: whole 16-byte words and not a power of two (the 256 rows are walked in lockstep by the transpose, the run
-// scan and the 16 chains of the gather pass; a precaution — 16 384-word rows measured the same, profiles/r04_ls_rocprof_stride.txt)
-inline uint32_t ls_nt_pad_for(uint32_t max_keys) { return ((div_up(max_keys, gs::LS_TILE) + 15u) & ~15u) + 272u; }
-// tables of the local-sort plan, words: R[256][nt_pad] | the first kernel's rows [nt_pad][256] | E[256][nt_pad] | S
-inline size_t ls_table_words(uint32_t max_keys) { const size_t p = ls_nt_pad_for(max_keys); return 3 * (size_t)gs::RADIX * p + gs::ls_stab_words((uint32_t)p); }
-#endif  // GS_TUNING
 
 // ---- two-level plan (hybrid_kernels.hpp) ----
 using HyHistLauncher = void (*)(hipStream_t, uint32_t grid, const uint32_t* keys, uint32_t* slab, size_t used_words, uint32_t n, uint32_t seg_len0,
@@ -251,9 +215,6 @@ const HyLocalLauncher g_hy_local[4][3] = {{launch_hy_local<0, 256, 12>, launch_h
                                           {launch_hy_local<0, 512, 12>, launch_hy_local<1, 512, 12>, launch_hy_local<2, 512, 12>},
                                           {launch_hy_local<0, 1024, 12>, launch_hy_local<1, 1024, 12>, launch_hy_local<2, 1024, 12>},
                                           {launch_hy_local<0, 1024, 24>, launch_hy_local<1, 1024, 24>, launch_hy_local<2, 1024, 24>}};
-#endif
-#ifdef GS_TUNING  // other shapes of the 6144-key class (debug_flags & 7 = 1, 2; u32 keys)
-const HyLocalLauncher g_hy_local_alt[2] = {launch_hy_local<0, 256, 24>, launch_hy_local<0, 1024, 6>};
 #endif
 using HyLocalPairsLauncher = void (*)(hipStream_t, uint32_t* keys, void* vals, const uint32_t* tab, const uint32_t* slab, uint32_t n, uint32_t descending);
 template <int KT, int VB, int T, int K>
@@ -294,6 +255,7 @@ struct gs_onesweep {
     uint32_t* slab;
     size_t slab_words;
     uint32_t* partials;  // the histogram workgroups' tables: hist_blocks(max_keys) x HIST_TABLE_WORDS, summed by hist_reduce_kernel
+    size_t partials_words;
     int profiling;
     hipEvent_t ev[GS_PROFILE_SLOTS + 1];
     bool ev_valid;
@@ -306,7 +268,6 @@ struct gs_onesweep {
     // geometry of the last tiled call, for gs_debug_check_state (tile 0 = the last call left no scan state)
     uint32_t last_n, last_tile, last_tile0, last_p0, last_np, last_dyn, last_desc_stride, last_pos_tile = 0;
     bool hist_dirty;   // a call failed between the histogram launch and the kernel that hands HIST back zeroed
-    // local-sort plan (ls_kernels.hpp): keys-only sorts of 32-bit keys from ls_min_keys up
     uint32_t hist_blocks_opt;  // gs_onesweep_options::hist_blocks (0 = the library picks)
     int first_pass_big;        // gs_onesweep_options::first_pass_big
     uint32_t debug_flags;      // gs_onesweep_options::debug_flags
@@ -315,12 +276,6 @@ struct gs_onesweep {
     uint32_t* hy_tab;      // the two-level plan's tables (gs::HYT_WORDS), nullptr: the handle cannot run it (pairs, 64-bit keys only ...)
     uint32_t hy_grid;      // workgroups of its histogram kernel (a multiple of NCH)
     int last_hy;           // the last sort was enqueued with the two-level plan's launches (whether it RAN on it is the device's decision: gs_onesweep_last_plan)
-#ifdef GS_TUNING
-    int ls_plan;           // 1 = the local-sort plan for eligible sorts (gs_onesweep_set_plan 3 / 4), 0 = never (default)
-    uint32_t ls_min_keys;
-    uint32_t* ls_runs;     // run table of the first kernel: [256][ls_nt_pad] words
-    uint32_t ls_nt_pad;
-#endif
     bool exp_keep_desc;  // experiment builds (GS_EXP & 1024): the histogram kernel leaves the descriptor rows alone
 };
 
@@ -601,52 +556,6 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         return GS_OK;
     }
 #endif
-#ifdef GS_TUNING
-    // Local-sort plan (ls_kernels.hpp; tuning build only): keys-only sorts of 32-bit keys on the default routing, LDS-atomic ranking.  Four launches:
-    // the first kernel sorts every tile locally by digit 0 (keys -> alt) and counts what the gather pass needs; gather pass
-    // (alt -> keys), two plain passes (keys -> alt -> keys).  No histogram sweep, no Scan launch: 32 bytes per key.
-    if (h->ls_plan && h->ls_runs && vb == 0 && !is_key64(kt) && h->rank_mode == 1 && h->shape_auto && h->skip_passes &&
-        (n >= h->ls_min_keys || h->ls_plan == 2) && g_ls_first[kt] != nullptr) {
-        const uint32_t nt = div_up(n, gs::LS_TILE);
-        const uint32_t rows1 = gs::ls_gather_rows(nt), rows23 = gs::ls_linear_rows(nt);
-        const uint32_t d1 = SLAB_DESC, d2 = d1 + rows1 * gs::RADIX, d3 = d2 + rows23 * gs::RADIX;
-        const size_t zero_end = (size_t)d3 + (size_t)rows23 * gs::RADIX;
-        if (zero_end > h->slab_words) return GS_ERR_SIZE;
-        h->msd_keys = nullptr;
-        const uint32_t grid = pos_grid();
-        if ((size_t)grid * gs::LS_SLICE_WORDS > (size_t)hist_blocks_cap(h->max_keys) * gs::HIST_TABLE_WORDS) return GS_ERR_SIZE;  // (cannot happen: 2 x CUs slices of 18 KiB in CUs x 128 KiB)
-        uint32_t* slices = h->partials;  // the workgroups' tables (the GlobalHistogram kernel's slices are not in use in this plan)
-        const uint32_t desc_bit = order == GS_ORDER_DESCENDING ? 1u : 0u;
-        uint32_t* ka = static_cast<uint32_t*>(d_keys);
-        uint32_t* kb = static_cast<uint32_t*>(d_alt_keys);
-        if (h->profiling)
-            for (int e = 0; e <= 3; ++e) GS_HIP(hipEventRecord(h->ev[e], s));  // (no clear, no histogram, no scan launch: slots 0..2 stay 0)
-        uint32_t* runs_t = h->ls_runs + (size_t)gs::RADIX * h->ls_nt_pad;  // the first kernel's rows [tile][256]; transposed into ls_runs
-        uint32_t* eprefix = runs_t + (size_t)gs::RADIX * h->ls_nt_pad;
-        uint32_t* stab = eprefix + (size_t)gs::RADIX * h->ls_nt_pad;
-        const uint32_t ls_exp = h->debug_flags;  // tuning bits (gs_onesweep_options::debug_flags)
-        // plan bits 8..15 of the first kernel: step of the rotated run layout (1 unless debug_flags bits 8..15 say otherwise; bit 17: off)
-        const uint32_t ls_rot = (ls_exp & 0x20000u) ? 0u : ((ls_exp & 0xff00u) ? (ls_exp & 0xff00u) : 0x100u);
-        g_ls_first[kt](s, grid, ka, kb, runs_t, slices, h->slab, zero_end, n, 2u | (ls_exp & ~0xff00u) | ls_rot);
-        const uint32_t tblocks = div_up(nt, 64u);
-        hipLaunchKernelGGL(gs::ls_plan_kernel, dim3(tblocks + gs::LS_SLICE_WORDS / 64u), dim3(gs::LS_RED_THREADS), 0, s, runs_t, h->ls_runs, nt, h->ls_nt_pad, tblocks,
-                           slices, grid, h->slab, 2u);
-        hipLaunchKernelGGL(gs::ls_runscan_kernel, dim3(gs::RADIX), dim3(1024), 0, s, h->ls_runs, eprefix, stab, nt, h->ls_nt_pad, h->slab);
-        if (h->profiling) GS_HIP(hipEventRecord(h->ev[4], s));
-        g_ls_pass[0][kt](s, grid, kb, ka, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d1, n, 1u, desc_bit | (ls_exp & 0x10000u));
-        hipLaunchKernelGGL(gs::ls_reduce_kernel, dim3(gs::NCH * gs::RADIX / 64u), dim3(gs::LS_RED_THREADS), 0, s, slices, grid, h->slab + gs::SLAB_HSUB + 2u * gs::HSUB_STRIDE);
-        if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));
-        g_ls_pass[1][kt](s, grid, ka, kb, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d2, n, 2u, desc_bit | (ls_exp & 0x10000u));
-        hipLaunchKernelGGL(gs::ls_reduce_kernel, dim3(gs::NCH * gs::RADIX / 64u), dim3(gs::LS_RED_THREADS), 0, s, slices, grid, h->slab + gs::SLAB_HSUB + 3u * gs::HSUB_STRIDE);
-        if (h->profiling) GS_HIP(hipEventRecord(h->ev[6], s));
-        g_ls_pass[2][kt](s, grid, kb, ka, h->ls_runs, eprefix, stab, h->ls_nt_pad, h->slab, slices, d3, n, 3u, desc_bit | (ls_exp & 0x10000u));
-        if (h->profiling) GS_HIP(hipEventRecord(h->ev[7], s));
-        GS_HIP(hipGetLastError());
-        h->last_tile = 0;     // (gs_debug_check_state: the plan keeps its own state)
-        h->profile_pending = h->profiling != 0;
-        return GS_OK;
-    }
-#endif  // GS_TUNING
     // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
     // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
     const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 &&
@@ -673,13 +582,13 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     const bool pos = dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
                      (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
                      (vb == 4 ? sh.threads * sh.kpt == 16384 : (sh.threads == 512 && sh.kpt == 32));  // (the plan's last pass runs on 16 384-key tiles)
-    // Two-level plan (hybrid_kernels.hpp): keys-only sorts of 32-bit keys that may also run on position chains (its fall-back when
-    // the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
+    // Two-level plan (hybrid_kernels.hpp): sorts of 32-bit keys — keys-only and pairs with 4- / 8-byte values — that may also run on
+    // position chains (its fall-back when the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
     // (position_chains = 2 asks for the position-chain plan whatever the keys look like: only plan 2 overrides that)
     const bool hy = pos && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
                     (h->plan == 2 || (n >= (vb ? HY_MIN_PAIRS_DEFAULT : h->hy_min_keys) && h->pos_chains != 2)) &&
                     (vb == 0 || (g_persist[vb == 8][kt] != nullptr && g_hy_local_pairs[vb == 8][hy_class(n)][kt] != nullptr)) &&
-                    (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, POS_TILE) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;
+                    (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, pos_tile_for(vb) & 0x7fffffffu) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;  // (prologue's row formula)
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
@@ -718,9 +627,6 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                 if (hy && p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
                     HyLocalLauncher local = g_hy_local[hy_class(n)][kt];
-#ifdef GS_TUNING
-                    if (hy_class(n) == 1 && kt == GS_KEY_UINT32 && (h->debug_flags & 7u) >= 1u && (h->debug_flags & 7u) <= 2u) local = g_hy_local_alt[(h->debug_flags & 7u) - 1u];
-#endif
                     // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is)
                     if (!(h->debug_flags & 0x40000000u)) local(s, gs::HY_BINS, k[0], h->hy_tab, h->slab, n, desc_bit);
                 }
@@ -849,11 +755,7 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
         if (options->struct_size != sizeof(gs_onesweep_options)) return GS_ERR_ARG;  // (one layout so far)
         o = *options;
     }
-#ifdef GS_TUNING
-    const int max_plan = 4;  // 3 / 4: the round-4 local-sort plan (at its own size / at every size)
-#else
     const int max_plan = 2;
-#endif
     if (o.rank_mode < -1 || o.rank_mode > 1 || o.position_chains < 0 || o.position_chains > 2 || o.plan < 0 || o.plan > max_plan ||
         (o.key64_sweeps != 1 && o.key64_sweeps != 2) || o.position_chains_min_log2 < 20 || o.position_chains_min_log2 > 30)
         return GS_ERR_ARG;
@@ -892,7 +794,7 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
 #if defined(GS_TUNING) || GS_EXP
     h->debug_flags = o.debug_flags;
 #else
-    h->debug_flags = o.debug_flags & 0x40000000u;  // the product build knows one bit (bring-up aid: skip the bucket-local sort); everything else belongs to tuning / experiment builds
+    h->debug_flags = 0;  // debug bits belong to tuning / experiment builds (bit 30 — skip the bucket-local sort, tools/hy_bringup.py — would hand back keys ordered on their top 16 bits only)
 #endif
     h->profiling = 0;
     h->ev_valid = false;
@@ -903,17 +805,11 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->msd_keys = nullptr;
     h->last_n = h->last_tile = h->last_tile0 = h->last_p0 = h->last_np = h->last_dyn = h->last_desc_stride = h->last_pos_tile = 0;
     h->hist_dirty = false;
-    h->plan = o.plan <= 2 ? o.plan : 0;
+    h->plan = o.plan;
     h->hy_min_keys = HY_MIN_KEYS_DEFAULT;
     h->hy_tab = nullptr;
     h->hy_grid = hy_grid_for_device();
     h->last_hy = 0;
-#ifdef GS_TUNING
-    h->ls_plan = 0;  // opt-in: slower than the default
-    h->ls_min_keys = (1u << 25) + 1u;  // (below: the 8192-key tile and the two-launch routes)
-    h->ls_runs = nullptr;
-    h->ls_nt_pad = ls_nt_pad_for(max_keys);
-#endif
     h->exp_keep_desc = false;
     h->msd_n = h->msd_grid = 0;
     h->msd_kt = GS_KEY_UINT32;
@@ -924,18 +820,14 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
     h->rank_mode = o.rank_mode >= 0 ? o.rank_mode : (lds_atomic_order_ok() ? 1 : 0);
     h->partials = nullptr;
     hipError_t e = hipMalloc(&h->slab, h->slab_words * sizeof(uint32_t));
-    // the two-level plan: keys-only handles that can hold a sort of its size class (the position-chain plan, its fall-back, starts at 2^20 keys)
-    const bool hy_handle = max_keys > (1u << 20) && o.plan != 1;
-    {
-        size_t slice_words = (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS;
-        if (hy_handle && (size_t)h->hy_grid * gs::HY_SLICE_WORDS > slice_words) slice_words = (size_t)h->hy_grid * gs::HY_SLICE_WORDS;
-        if (e == hipSuccess) e = hipMalloc(&h->partials, slice_words * sizeof(uint32_t));
-    }
+    // the two-level plan's tables (0.8 MiB) and its histogram slices (hy_grid x 129 KiB: 33 MiB on 256 CUs): only for handles the default
+    // routing can send there — keys-only and pairs handles that hold a sort of the plan's size — or that ask for plan 2 (tests, tools:
+    // wherever the position-chain plan, its fall-back, runs: from 2^20 keys); gs_onesweep_set_plan(2) allocates them on demand otherwise
+    const bool hy_handle = o.plan != 1 && (o.plan == 2 ? max_keys > (1u << 20) : max_keys >= (mode == GS_MODE_PAIRS ? HY_MIN_PAIRS_DEFAULT : HY_MIN_KEYS_DEFAULT));
+    h->partials_words = (size_t)hist_blocks_cap(max_keys, o.hist_blocks) * gs::HIST_TABLE_WORDS;
+    if (hy_handle && (size_t)h->hy_grid * gs::HY_SLICE_WORDS > h->partials_words) h->partials_words = (size_t)h->hy_grid * gs::HY_SLICE_WORDS;
+    if (e == hipSuccess) e = hipMalloc(&h->partials, h->partials_words * sizeof(uint32_t));
     if (e == hipSuccess && hy_handle) e = hipMalloc(&h->hy_tab, gs::HYT_WORDS * sizeof(uint32_t));
-#ifdef GS_TUNING
-    if (e == hipSuccess && mode == GS_MODE_KEYS_ONLY && max_keys >= h->ls_min_keys && o.plan >= 3)  // the run tables of the local-sort plan (48 MiB at 2^28 keys)
-        e = hipMalloc(&h->ls_runs, ls_table_words(max_keys) * sizeof(uint32_t));
-#endif
     // counters/status/info start defined: gs_onesweep_check() may run before any tiled sort (single-tile path)
     if (e == hipSuccess) e = hipMemset(h->slab, 0, SLAB_DESC * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&h->pinned, (4 * gs::NCH * gs::RADIX + 8) * sizeof(uint32_t), hipHostMallocDefault);
@@ -944,15 +836,9 @@ gs_status gs_onesweep_create_ex(gs_onesweep** out, uint32_t max_keys, gs_mode mo
         if (h->slab) (void)hipFree(h->slab);
         if (h->partials) (void)hipFree(h->partials);
         if (h->hy_tab) (void)hipFree(h->hy_tab);
-#ifdef GS_TUNING
-        if (h->ls_runs) (void)hipFree(h->ls_runs);
-#endif
         delete h;
         return GS_ERR_HIP;
     }
-#ifdef GS_TUNING
-    if (o.plan >= 3 && h->ls_runs) h->ls_plan = o.plan - 2;  // (a handle without the plan's tables stays on the default pipeline)
-#endif
     *out = h;
     return GS_OK;
 }
@@ -965,9 +851,6 @@ gs_status gs_onesweep_destroy(gs_onesweep* h) {
     if (h->slab) (void)hipFree(h->slab);
     if (h->partials) (void)hipFree(h->partials);
     if (h->hy_tab) (void)hipFree(h->hy_tab);
-#ifdef GS_TUNING
-    if (h->ls_runs) (void)hipFree(h->ls_runs);
-#endif
     delete h;
     return GS_OK;
 }
@@ -976,7 +859,7 @@ gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count
     // bit 31 of first_word: the workgroups' table slices (hist partials) instead of the slab
     const bool part = (first_word >> 31) != 0u;
     first_word &= 0x7fffffffu;
-    const size_t limit = part ? (size_t)hist_blocks_cap(h ? h->max_keys : 1u) * gs::HIST_TABLE_WORDS : (h ? h->slab_words : 0);
+    const size_t limit = part ? (h ? h->partials_words : 0) : (h ? h->slab_words : 0);
     if (!h || !h_out || (size_t)first_word + count > limit) return GS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     GS_HIP(hipMemcpyAsync(h_out, (part ? h->partials : h->slab) + first_word, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -986,16 +869,22 @@ gs_status gs_debug_read_slab(gs_onesweep* h, uint32_t first_word, uint32_t count
 
 gs_status gs_onesweep_set_plan(gs_onesweep* h, int plan) {
     if (!h || plan < 0) return GS_ERR_ARG;
-#ifdef GS_TUNING
-    if (plan == 3 || plan == 4) {  // the round-4 local-sort plan
-        if (!h->ls_runs) return GS_ERR_MODE;
-        h->ls_plan = plan - 2;
-        return GS_OK;
-    }
-    h->ls_plan = 0;
-#endif
     if (plan > 2) return GS_ERR_ARG;
-    if (plan == 2 && !h->hy_tab) return GS_ERR_MODE;  // (the handle was created without the plan's tables: max_keys <= 2^20, or plan 1 at create)
+    if (plan == 2 && !h->hy_tab) {
+        // the handle was created without the plan's tables (below the plan's default size, or plan 1): allocate them now.  The caller
+        // must not have a sort of this handle in flight (as for every setter): the slices are re-allocated.
+        if (h->max_keys <= (1u << 20)) return GS_ERR_MODE;  // (the plan's fall-back, the position-chain plan, starts above 2^20 keys)
+        const size_t need = (size_t)h->hy_grid * gs::HY_SLICE_WORDS;
+        if (need > h->partials_words) {
+            uint32_t* p = nullptr;
+            GS_HIP(hipDeviceSynchronize());
+            GS_HIP(hipMalloc(&p, need * sizeof(uint32_t)));
+            (void)hipFree(h->partials);
+            h->partials = p;
+            h->partials_words = need;
+        }
+        GS_HIP(hipMalloc(&h->hy_tab, gs::HYT_WORDS * sizeof(uint32_t)));
+    }
     h->plan = plan;
     return GS_OK;
 }

@@ -32,7 +32,7 @@
 //   * a sort on the LSD plan is 7 launches: GlobalHistogram (which also clears the scan state), the sum of its workgroups' tables,
 //     Scan, 4 x DigitBinningPass.  Large sorts are offered the TWO-LEVEL plan (hybrid_kernels.hpp: the same DigitBinningPass on bytes
 //     3 and 2 — told its digit and chain count by the info block — then bucket-local LDS sorts of the low 16 bits: 28 B/key instead of
-//     36), chosen per sort on the device.  (ls_kernels.hpp: round 4's local-sort-first plan, tuning build only.)
+//     36), chosen per sort on the device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -177,15 +177,11 @@ constexpr uint32_t HSUB_STRIDE = (NCH + 1) * RADIX;  // per pass
 // claim / flag words, two count tables of MID_MAX_TILES rows
 constexpr uint32_t SLAB_MID = SLAB_HSUB + 4 * HSUB_STRIDE;
 constexpr uint32_t SLAB_MID_WORDS = 2048 + 2 * 256 * RADIX;
-// LS: what the local-sort plan (ls_kernels.hpp) keeps beside CNEXT: digit-0 totals, OR / AND of the keys, its first kernel's
-// arrival counter, the plan flags and the gather pass's unit geometry
-constexpr uint32_t SLAB_LS = SLAB_MID + SLAB_MID_WORDS;
-constexpr uint32_t SLAB_LS_WORDS = 1024;
 // HY: the two-level plan's words (hybrid_kernels.hpp): valid flag, largest bucket
-constexpr uint32_t SLAB_HY = SLAB_LS + SLAB_LS_WORDS;
+constexpr uint32_t SLAB_HY = SLAB_MID + SLAB_MID_WORDS;
 constexpr uint32_t SLAB_HY_WORDS = 32;
 constexpr uint32_t SLAB_DESC = SLAB_HY + SLAB_HY_WORDS;
-static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_LS % 4 == 0 && SLAB_HY % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
+static_assert(SLAB_HIST % 4 == 0 && SLAB_HSUB % 4 == 0 && SLAB_MID % 4 == 0 && SLAB_HY % 4 == 0 && SLAB_DESC % 4 == 0, "regions are cleared with 16-byte stores");
 #ifndef GS_GHIST_THREADS
 #define GS_GHIST_THREADS 1024
 #endif
@@ -1002,7 +998,12 @@ __device__ __forceinline__ void binning_body(
     // time ~NCH chains are live with 32 workgroups each, exactly the LSD passes' picture: every (chain, digit) write cursor is fed by
     // a whole row of neighbouring tiles (with all 256 chains live at once, two workgroups each, the pass wrote through 65 536 cursors
     // with two tiles behind each and ran at 0.66 ms instead of 0.47: DRAM pages served 512 bytes per activation, profiles/r05_*).
-    const uint32_t ngroups = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) / NCH : 1u;
+#ifndef GS_HY_GROUP_CHAINS
+#define GS_HY_GROUP_CHAINS NCH  // chains of a CHMAX-chain pass that are live at a time (a power of two >= NCH)
+#endif
+    const uint32_t nch_info = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) : NCH;
+    const uint32_t gchains = nch_info > NCH ? (uint32_t)GS_HY_GROUP_CHAINS : NCH;  // uniform
+    const uint32_t ngroups = (mode & 256u) ? nch_info / gchains : 1u;
     uint32_t group = 0;  // uniform; persistent workgroups keep it across their tiles
     static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || VB == 4 || (VB == 8 && VR == 2))),
                   "the position-chain forms exist for 32-bit keys, keys-only, with 4-byte values (staged behind the keys) or with 8-byte values (two staging rounds), LDS-atomic ranking");
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void binning_body(
     // chain blockIdx % NCH (each counter has its own cache line).  Ticket order inside
     // a chain is the start order, so every predecessor of a claimed tile is running.
     // Only when that chain is already fully claimed does thread 0 try the others. ----
-    uint32_t chain = (blockIdx.x & (NCH - 1)) + group * NCH;
+    uint32_t chain = (blockIdx.x & (gchains - 1u)) + group * gchains;
     // geometry of the fast-path chain: requested before the ticket is (scalar loads that depend on blockIdx only), so
     // their round trip runs beside the ticket atomic's instead of after the barrier
     const uint32_t seg_start_f = info[I_START + chain], seg_end_f = info[I_END + chain], row_f = info[I_ROW + chain];

@@ -172,8 +172,9 @@ class OneSweep:
         check(self._lib.gs_onesweep_set_skip_passes(self._h, 1 if on else 0), "gs_onesweep_set_skip_passes")
 
     def set_plan(self, plan) -> None:
-        """Large keys-only sorts of 32-bit keys: 0 the library picks (two-level plan from 3 x 2^24 keys up when the device finds the
-        keys near-uniform, LSD passes otherwise), 1 the four LSD passes only, 2 the two-level plan wherever it can run (tests)."""
+        """Large sorts of 32-bit keys, keys-only and pairs (4- / 8-byte values): 0 the library picks (two-level plan from 3 x 2^24 keys /
+        2^25 + 1 pairs up when the device finds the keys near-uniform, LSD passes otherwise), 1 the four LSD passes only, 2 the
+        two-level plan wherever it can run (tests)."""
         check(self._lib.gs_onesweep_set_plan(self._h, int(plan)), "gs_onesweep_set_plan")
 
     def last_plan(self) -> dict:

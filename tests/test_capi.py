@@ -52,7 +52,7 @@ def test_library_reads_no_environment():
     if out.returncode != 0:
         pytest.skip("no nm on this box")
     assert "getenv" not in out.stdout
-    for f in ("gpusort_capi.hip", "gpusort_mgpu.hpp", "onesweep_kernels.hpp", "ls_kernels.hpp", "mid_kernels.hpp", "msd_kernels.hpp"):
+    for f in ("gpusort_capi.hip", "gpusort_mgpu.hpp", "onesweep_kernels.hpp", "hybrid_kernels.hpp", "mid_kernels.hpp", "msd_kernels.hpp"):
         assert "getenv" not in open(os.path.join(ROOT, "gpusorting_amd", "csrc", f)).read(), f
 
 
