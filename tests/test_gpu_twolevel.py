@@ -112,17 +112,32 @@ def test_two_level_plan_back_to_back_with_other_plans(gpu, oracle, sorters):
         np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), np.sort(k))
 
 
-def test_two_level_plan_needs_its_tables(gpu):
+def test_two_level_plan_needs_its_tables(gpu, oracle):
+    """A handle that the default routing can never send to the two-level plan (below its size, or created with plan 1) carries no tables
+    for it (34 MB per handle saved); gs_onesweep_set_plan(2) allocates them on demand — and the next sort runs on the plan,
+    exactly — except where the plan's fall-back does not exist either (max_keys <= 2^20)."""
+    import torch
     s = gpu.OneSweep(1 << 20)
     with pytest.raises(Exception):
-        s.set_plan(2)      # max_keys <= 2^20: the handle has no tables for the plan
+        s.set_plan(2)      # max_keys <= 2^20: neither the plan nor its fall-back (position chains) runs there
     s.set_plan(0)
     s.set_plan(1)
     s.close()
-    p = gpu.OneSweep(MAXK, plan=1)
-    with pytest.raises(Exception):
-        p.set_plan(2)      # created with plan 1: no tables
-    p.close()
+    for kwargs in ({"plan": 1}, {}):    # created with plan 1; created on default routing below the plan's size
+        n = (1 << 22) + 321
+        p = gpu.OneSweep(n, small_path=0, mid_path=0, position_chains_min_log2=20, **kwargs)
+        keys = oracle.init_random(n, 77, 0)
+        dk = torch.from_numpy(keys.view(np.int32)).cuda()
+        p.sort(dk)
+        p.check()
+        assert not p.last_plan()["two_level"]
+        p.set_plan(2)      # tables (and the larger histogram slices) allocated now
+        dk = torch.from_numpy(keys.view(np.int32)).cuda()
+        p.sort(dk)
+        p.check()
+        assert p.last_plan()["two_level"]
+        np.testing.assert_array_equal(dk.cpu().numpy().view(np.uint32), np.sort(keys))
+        p.close()
 
 
 # ---- pairs: the values go through both DigitBinningPasses with their keys and once more through the bucket-local sort ------------
