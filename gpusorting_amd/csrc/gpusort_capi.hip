@@ -374,7 +374,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
     // (two-level plan: its second pass runs on CHMAX chains)
     const uint32_t rows = ((scan_plan & 4u) && (pos_tile & 0x7fffffffu) < tile ? div_up(n, pos_tile & 0x7fffffffu) : tiles) + (hy ? 2 * gs::CHMAX + 8 : 2 * gs::MAXCH + 2);
     const uint32_t desc_stride = rows * gs::RADIX;
-    // (hy: the descriptor regions of LSD passes 2 and 3 are zeroed by the launch of LSD pass 1 (mode bit 9) if — and only if — those passes run)
+    // (hy: the descriptor regions of LSD passes 2 and 3 are zeroed by the launch of LSD pass 1 (BM_ZERO_DESC23) if — and only if — those passes run)
     const size_t used_words = h->exp_keep_desc ? (size_t)SLAB_DESC : SLAB_DESC + (size_t)(hy ? 2u : np) * desc_stride;
     if (SLAB_DESC + (size_t)np * desc_stride > h->slab_words) return GS_ERR_SIZE;  // (cannot happen with the tiles the library picks)
     // position segments of the first pass: equal, multiples of the histogram chunk — and of the first pass's tile where that is a
@@ -614,16 +614,16 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
         for (uint32_t p = 0; p < NP; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
-            const uint32_t mode = (dyn ? (desc_bit | 2u) : ((desc_bit && p == NP - 1) ? 1u : 0u)) | (p == 0 ? 4u : 0u);
+            const uint32_t mode = (dyn ? (desc_bit | gs::BM_PLANNED) : ((desc_bit && p == NP - 1) ? gs::BM_REVERSE : 0u)) | (p == 0 ? gs::BM_ZERO_HIST : 0u);
             // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
             const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
             if (pos && vb == 0) {  // one launch serves both plans (persistent workgroups, two per CU)
                 // two-level plan: the first two launches are pass A / pass B or LSD passes 0 / 1 — digit and chain count come from the
-                // info block (mode bits 7, 8); the bucket-local sort follows them; LSD passes 2 and 3 exit on PF_SKIP if it ran
+                // info block (BM_INFO_SHIFT, BM_INFO_CHAINS); the bucket-local sort follows them; LSD passes 2 and 3 exit on PF_SKIP if it ran
                 g_dual[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
-                                   mode | ((hy && p < 2) ? 128u | 256u : 0u) | ((hy && p == 1) ? 512u : 0u));
+                                   mode | ((hy && p < 2) ? gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS : 0u) | ((hy && p == 1) ? gs::BM_ZERO_DESC23 : 0u));
                 if (hy && p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
                     HyLocalLauncher local = g_hy_local[hy_class(n)][kt];
@@ -640,9 +640,9 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                 const uint32_t* i_p = h->slab + SLAB_INFO + p * gs::INFO_STRIDE;
                 if (p < 2)
                     g_persist[vb == 8][kt](s, pos_grid() / 2u, k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                           p * 8, mode | 64u | 128u | 256u);
+                                           p * 8, mode | gs::BM_FORMS | gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS);
                 g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                            p * 8, (mode & ~4u) | 64u | (p == 1 ? 512u : 0u));
+                                            p * 8, (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS | (p == 1 ? gs::BM_ZERO_DESC23 : 0u));
                 if (p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));
                     if (!(h->debug_flags & 0x40000000u)) g_hy_local_pairs[vb == 8][hy_class(n)][kt](s, k[0], v[0], h->hy_tab, h->slab, n, desc_bit);
@@ -651,23 +651,23 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                 (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
-                   mode | (two_forms ? 32u : 0u) | ((pos && vb != 0) ? 64u : 0u) | exp_mode);
+                   mode | (two_forms ? gs::BM_IF_EVEN : 0u) | ((pos && vb != 0) ? gs::BM_FORMS : 0u) | exp_mode);
             if (two_forms && !hy)
                 g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                         h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                         h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                        word * 32 + p * 8, mode | 16u | ((pos && vb == 8) ? 64u : 0u));
+                                        word * 32 + p * 8, mode | gs::BM_IF_SKEW | ((pos && vb == 8) ? gs::BM_FORMS : 0u));
             if (pos && vb != 0 && !hy)  // pairs: the position-chain form is a launch of its own (the plan's flags pick one of the two or three)
                 g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
                                    h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
                                    h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
-                                   (mode & ~4u) | 64u);
+                                   (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS);
             if (h->profiling && word == 0 && p < 4 && !(hy && p == 1)) GS_HIP(hipEventRecord(h->ev[4 + p], s));
         }
     }
     if (h->profiling && is_key64(kt)) GS_HIP(hipEventRecord(h->ev[7], s));  // slot 6 then holds pass 3 and everything behind it
     GS_HIP(hipGetLastError());
-    h->hist_dirty = false;  // pass 0 (mode bit 2) was launched: it zeroes HIST
+    h->hist_dirty = false;  // pass 0 (BM_ZERO_HIST) was launched: it zeroes HIST
     h->profile_pending = h->profiling != 0;
     return GS_OK;
 }
@@ -1131,7 +1131,7 @@ gs_status gs_onesweep_digit_pass(gs_onesweep* h, const void* d_keys_in, void* d_
     fn(s, plan.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
        h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, pass * 8,
-       (reverse_index ? 1u : 0u) | 4u);
+       (reverse_index ? gs::BM_REVERSE : 0u) | gs::BM_ZERO_HIST);
     GS_HIP(hipGetLastError());
     h->hist_dirty = false;
     if (h->profiling)  // slot 3 = this pass, slots 4..6 = 0
@@ -1182,7 +1182,7 @@ gs_status gs_onesweep_msd_partition(gs_onesweep* h, const void* d_keys_in, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     fn(s, h->msd_grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys_in)), static_cast<uint32_t*>(d_keys_out),
        const_cast<void*>(d_vals_in), d_vals_out,
-       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, 24, 4u);
+       h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, 24, gs::BM_ZERO_HIST);
     GS_HIP(hipGetLastError());
     h->msd_keys = nullptr;  // the scan state is consumed
     h->profile_pending = false;

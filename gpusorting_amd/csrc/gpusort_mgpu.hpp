@@ -469,7 +469,7 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
             } else if (!fine) {
                 fn(s, pp.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys)), c->part_keys, const_cast<void*>(d_vals),
                    c->part_vals, h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB,
-                   h->slab + SLAB_STATUS, n, 24, 4u);
+                   h->slab + SLAB_STATUS, n, 24, gs::BM_ZERO_HIST);
                 if (hipGetLastError() != hipSuccess) local = GS_ERR_HIP;
                 h->hist_dirty = false;
             } else {  // order by the top two bytes: every 12-bit prefix range is contiguous (the output buffers are the scratch)

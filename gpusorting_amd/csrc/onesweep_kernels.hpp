@@ -972,6 +972,21 @@ struct BinCfg {
 
 // The pass as a device function: one tile (PERSIST = false: one workgroup per tile, the grid covers the tiles) or tile after
 // tile until every chain is claimed (PERSIST = true).  s_raw: Cfg::LDS_BYTES of LDS.
+// Mode word of a DigitBinningPass launch: what the HOST knows about the launch (everything the DEVICE decided is in the pass's flag
+// word PF_* of its info block).  One launch carries at most the bits of its family: plain passes BM_REVERSE / BM_PLANNED /
+// BM_ZERO_HIST (+ BM_IF_SKEW / BM_IF_EVEN for the two forms of the 8-byte-value pass); launches of a sort that may run on position
+// chains add BM_FORMS; the two launches the two-level plan shares with the LSD plan add BM_INFO_SHIFT / BM_INFO_CHAINS / BM_ZERO_DESC23.
+constexpr uint32_t BM_REVERSE = 1;        // descending: reversed output index — with BM_PLANNED only on the plan's last pass (PF_LAST)
+constexpr uint32_t BM_PLANNED = 2;        // part of a full sort: the flag word decides whether the pass runs (PF_SKIP) and which buffer it reads (PF_SRC_ALT)
+constexpr uint32_t BM_ZERO_HIST = 4;      // first pass launched after the Scan: hands the HIST region back zeroed (see global_histogram_kernel)
+constexpr uint32_t BM_IF_SKEW = 16;       // one of two forms of the pass: works only if the pass is flagged PF_SKEW ...
+constexpr uint32_t BM_IF_EVEN = 32;       // ... only if it is not
+constexpr uint32_t BM_FORMS = 64;         // the pass is also launched in its position-chain form: this launch works only if PF_POS matches its POS
+constexpr uint32_t BM_INFO_SHIFT = 128;   // the digit's bit position comes from the info block (I_SHIFT), not from shift_full
+constexpr uint32_t BM_INFO_CHAINS = 256;  // the chain count comes from the info block BEFORE the first ticket (I_NCH may be CHMAX: the two-level plan's second pass)
+constexpr uint32_t BM_ZERO_DESC23 = 512;  // LSD pass 1 of a sort that was offered the two-level plan: zeroes the descriptor regions of passes 2 and 3 if the LSD plan runs
+// (experiment builds, GS_EXP & 1024 / 2048, reuse bits 256 .. 2048 as run-time ablation switches of plain LSD launches: onesweep_ablation.hpp)
+
 template <int THREADS, int KPT, int VB, int KT, int RANK, int VR, int POS, bool PERSIST>
 __device__ __forceinline__ void binning_body(
     unsigned char* s_raw,
@@ -981,17 +996,10 @@ __device__ __forceinline__ void binning_body(
     const uint32_t* info,    // this pass: the info block written by scan_kernel
     uint32_t* hsub,          // SLAB_HSUB = CNEXT (PF_POS sorts): read [this pass], added to [the next pass that runs]
     uint32_t* status, uint32_t n, uint32_t shift_full /*bit position of the digit in the key: 0..24, 64-bit keys 0..56*/,
-    uint32_t mode /*bit0: reversed output index; bit1: part of a full sort — the flag word decides whether the pass
-                    runs at all (PF_SKIP), whether it reads b and writes a (PF_SRC_ALT), and bit0 only counts
-                    on the last pass that runs (PF_LAST); bit2: zero the HIST region; bit4 / bit5: this launch is one of two
-                    forms of the pass — it runs only if the pass is flagged PF_SKEW (bit4) / only if it is not (bit5); bit6: the
-                    pass is also launched in its position-chain form — this launch works only if the plan's PF_POS matches its POS
-                    (checked first); bit7: the digit's bit position comes from the info block (I_SHIFT), not from shift_full; bit8: the
-                    chain count comes from the info block BEFORE the first ticket (I_NCH may be CHMAX: the two-level plan's second pass) —
-                    sorts whose plan (LSD passes or the two-level plan) the Scan kernels choose on the device; bit9: see below*/) {
+    uint32_t mode /*BM_* bits, above*/) {
     constexpr int KW = KeyWords<KT>::value;
     using Cfg = BinCfg<THREADS, KPT, VB, KW, VR, POS>;
-    if (mode & 128u) shift_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_SHIFT]);
+    if (mode & BM_INFO_SHIFT) shift_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_SHIFT]);
     // Chain a workgroup asks first: blockIdx modulo NCH, in chain GROUP `group`.  The LSD plans have one group (NCH chains).  A pass on
     // CHMAX chains (the two-level plan's second pass: one chain per top-byte bucket) is walked group by group — NCH chains at a time,
     // each by the 1 / NCH of the workgroups that share its lane, moving on to chain + NCH when it is fully claimed — so that at any
@@ -1001,9 +1009,9 @@ __device__ __forceinline__ void binning_body(
 #ifndef GS_HY_GROUP_CHAINS
 #define GS_HY_GROUP_CHAINS NCH  // chains of a CHMAX-chain pass that are live at a time (a power of two >= NCH)
 #endif
-    const uint32_t nch_info = (mode & 256u) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) : NCH;
+    const uint32_t nch_info = (mode & BM_INFO_CHAINS) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_NCH]) : NCH;
     const uint32_t gchains = nch_info > NCH ? (uint32_t)GS_HY_GROUP_CHAINS : NCH;  // uniform
-    const uint32_t ngroups = (mode & 256u) ? nch_info / gchains : 1u;
+    const uint32_t ngroups = (mode & BM_INFO_CHAINS) ? nch_info / gchains : 1u;
     uint32_t group = 0;  // uniform; persistent workgroups keep it across their tiles
     static_assert(!POS || (KW == 1 && RANK == 1 && (VB == 0 || VB == 4 || (VB == 8 && VR == 2))),
                   "the position-chain forms exist for 32-bit keys, keys-only, with 4-byte values (staged behind the keys) or with 8-byte values (two staging rounds), LDS-atomic ranking");
@@ -1036,12 +1044,12 @@ __device__ __forceinline__ void binning_body(
                                                            // POS == 1: [4] the next digit this workgroup does NOT count (see count_next), [5] its election, [8..23] keys written per output segment
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    if (mode & 4u) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
+    if (mode & BM_ZERO_HIST) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
         // (grid-stride: a small grid of a 256-thread tuning shape does not cover the 8200 16-byte words with one store per thread)
         for (uint32_t i = blockIdx.x * THREADS + tid; i < HIST_WORDS / 4; i += gridDim.x * THREADS)
             reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
     }
-    if (mode & 512u) {
+    if (mode & BM_ZERO_DESC23) {
         // A sort that was offered the two-level plan and runs on the LSD passes after all (PF_POS is set): the histogram kernel zeroed
         // only the descriptor regions both plans use (passes 0 and 1); this launch — LSD pass 1 — zeroes the regions of passes 2 and 3
         // beside its own work (they lie behind its own region; nobody touches them before pass 2 starts).
@@ -1051,11 +1059,11 @@ __device__ __forceinline__ void binning_body(
             for (uint32_t i = blockIdx.x * THREADS + tid; i < stride / 2u; i += gridDim.x * THREADS) z[i] = uint4{0u, 0u, 0u, 0u};  // 2 x stride words
         }
     }
-    if (mode & 48u) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
+    if (mode & (BM_IF_SKEW | BM_IF_EVEN)) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
         const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
-        if (skewed != ((mode & 16u) != 0u)) return;
+        if (skewed != ((mode & BM_IF_SKEW) != 0u)) return;
     }
-    if (mode & 64u) {  // the pass is launched in several forms: the plan says whether the position-chain form or the others work
+    if (mode & BM_FORMS) {  // the pass is launched in several forms: the plan says whether the position-chain form or the others work
         const bool planned_pos = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) != 0;
         if (planned_pos != (POS != 0)) return;
     }
@@ -1097,7 +1105,7 @@ __device__ __forceinline__ void binning_body(
         }
     }
     // (POS == 1) the digit position this workgroup counts for, ~0: none — the same word every tile reads below as next_shift
-    const uint32_t guard_ns = (POS == 1 && (mode & 2u)) ? uni(info[I_NEXT_SHIFT]) : 0xffffffffu;
+    const uint32_t guard_ns = (POS == 1 && (mode & BM_PLANNED)) ? uni(info[I_NEXT_SHIFT]) : 0xffffffffu;
     GS_TRACE_SETUP();
     // (measured and not kept, PERSIST: the next tile's ticket drawn while this tile is scattered — +0.5 .. 1 %: a tile claimed
     //  4 us before its workgroup starts on it publishes its counts 4 us late for the tiles behind it,
@@ -1155,20 +1163,20 @@ __device__ __forceinline__ void binning_body(
     // each and a 64-bit vector add per access, and every branch on them is an exec-mask branch).
     if (uni(s_misc[3]) != STATUS_OK) break;
     const uint32_t pflags = uni(s_misc[9]) | (pos_skew ? PF_SKEW : 0u);
-    if ((mode & 2u) && (pflags & PF_SKIP)) break;  // identity pass of a full sort
+    if ((mode & BM_PLANNED) && (pflags & PF_SKIP)) break;  // identity pass of a full sort
 #ifdef GS_STATIC_IO  // A/B aid: the pass always reads a and writes b (run with skip_passes = 0)
     const bool swapped = false;
 #else
-    const bool swapped = (mode & 2u) && (pflags & PF_SRC_ALT);
+    const bool swapped = (mode & BM_PLANNED) && (pflags & PF_SRC_ALT);
 #endif
     const uint32_t* keys_in = swapped ? keys_b : keys_a;
     uint32_t* keys_out = swapped ? keys_a : keys_b;
     const void* vals_in_ = swapped ? vals_b : vals_a;
     void* vals_out_ = swapped ? vals_a : vals_b;
-    const bool reverse = (mode & 1u) && (!(mode & 2u) || (pflags & PF_LAST));
+    const bool reverse = (mode & BM_REVERSE) && (!(mode & BM_PLANNED) || (pflags & PF_LAST));
     const uint32_t nch = uni(s_misc[10]);                                 // chains of this pass
     // POS: bit position of the next running pass's digit (~0: nothing to count) and log2 of its position segments
-    const uint32_t next_shift = (POS == 1 && (mode & 2u)) ? uni(s_misc[11]) : 0xffffffffu, seglog = uni(s_misc[12]);
+    const uint32_t next_shift = (POS == 1 && (mode & BM_PLANNED)) ? uni(s_misc[11]) : 0xffffffffu, seglog = uni(s_misc[12]);
     uint32_t tile = uni(s_misc[1]);
     // A chain's tile grid starts at its segment start rounded DOWN to 64 keys, so every
     // wave-load is 256-byte aligned; keys in front of the segment are masked like the tail.
@@ -1930,7 +1938,7 @@ __device__ __forceinline__ void binning_body(
     if constexpr (POS == 1) {
         // hand the counts to the next pass that runs: CNEXT[that pass][segment][digit] += this workgroup's table
         const uint32_t ns = uni(info[I_NEXT_SHIFT]);
-        if ((mode & 2u) && ns != 0xffffffffu && !(uni(info[PASS_FLAGS]) & PF_SKIP)) {
+        if ((mode & BM_PLANNED) && ns != 0xffffffffu && !(uni(info[PASS_FLAGS]) & PF_SKIP)) {
             __syncthreads();
             const uint32_t left_out = uni(s_pos[4]);
             uint32_t* cn_out = hsub + (ns >> 3) * HSUB_STRIDE;
