@@ -121,6 +121,7 @@ _PROTOS = [
     ("gs_onesweep_set_plan", _int, [_vp, _int]),
     ("gs_onesweep_last_plan", _int, [_vp, _u32p, _u32p, _vp]),
     ("gs_selftest_lds_atomic_order", _int, [_u32, _u32, C.POINTER(C.c_uint64), _vp]),
+    ("gs_selftest_wave_primitives", _int, [_u32, _u32, _vp, _vp]),
     ("gs_debug_set_trace", _int, [_vp, _vp]),
     ("gs_debug_check_state", _int, [_vp, C.POINTER(C.c_uint64), _vp]),
     ("gs_debug_poke_status", _int, [_vp, _u32, _vp]),

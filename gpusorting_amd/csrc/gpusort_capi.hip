@@ -964,6 +964,13 @@ gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* 
     return ret;
 }
 
+gs_status gs_selftest_wave_primitives(uint32_t seed, uint32_t waves, uint32_t* d_out, void* stream) {
+    if (!d_out || waves == 0 || (waves & 3u) != 0u || waves > (1u << 20)) return GS_ERR_ARG;
+    hipLaunchKernelGGL(gs::wave_primitives_kernel, dim3(waves / 4u), dim3(256), 0, static_cast<hipStream_t>(stream), seed, d_out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 #ifdef GS_TUNING
 // Tuning aid: global access pattern of a DigitBinningPass without ranking or look-back (memory floor of the tile shape);
 // threads == 0: plain streaming copies (kpt 0 / 1 / 2 = default / nt loads / nt loads and stores) and a read-only sweep (kpt 3).

@@ -2249,6 +2249,45 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(uint32_t* key
 // back-to-back ds_add_rtn on a private 256-counter table and compares each
 // returned value with the exact stable rank computed with ballots.
 // ---------------------------------------------------------------------------
+// Self-test of the wave-level primitives the kernels are built from — the wave64 counterparts of the reference's warp primitives
+// (GPUSortingCUDA/Utils.cuh:22-126: getLaneId / getLaneMaskLt by PTX, Inclusive / ExclusiveWarpScan by __shfl_up_sync,
+// WarpReduceSum; the 32-lane ballot multi-split of OneSweep.cu:207-253).  Every lane of every wave takes the word
+// x = wave_primitive_input(seed, wave * 64 + lane) and writes, per wave, eight rows of 64 words:
+//   0 x   1 wave_inclusive_scan(x & 0xffff) (shuffles)   2 wave_inclusive_scan_dpp(x & 0xffff)   3 wave_reduce_sum(x & 0xffff), lane 0's
+//   4 / 5 low / high word of the 64-bit ballot of (x & 1)   6 mbcnt of that ballot = set lanes BELOW this lane (the lanemask_lt popcount)
+//   7 rank of the lane among the lanes that hold the same low byte, by the eight-ballot multi-split of binning_body's RANK == 0 path
+// tests/test_gpu_parity.py recomputes all of it on the host.
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t wave_primitive_input(uint32_t seed, uint32_t i) {
+    uint32_t h = (seed ^ (i * 2654435761u)) * 2246822519u;
+    h ^= h >> 13;
+    h *= 3266489917u;
+    return h ^ (h >> 16);
+}
+__global__ __launch_bounds__(256) void wave_primitives_kernel(uint32_t seed, uint32_t* __restrict__ out) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = blockIdx.x * 4u + (tid >> 6);
+    const uint32_t x = wave_primitive_input(seed, wave * 64u + lane);
+    uint32_t* row = out + (size_t)wave * 8u * 64u;
+    row[lane] = x;
+    row[64 + lane] = wave_inclusive_scan(x & 0xffffu, lane);
+    row[128 + lane] = wave_inclusive_scan_dpp(x & 0xffffu);
+    row[192 + lane] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_reduce_sum(x & 0xffffu));
+    const unsigned long long b = __builtin_amdgcn_ballot_w64((x & 1u) != 0u);
+    row[256 + lane] = (uint32_t)b;
+    row[320 + lane] = (uint32_t)(b >> 32);
+    row[384 + lane] = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    uint32_t acc_lo = 0, acc_hi = 0;  // bit l set <=> lane l's low byte differs from mine
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)x, k, 1);  // 0 or ~0
+        const unsigned long long bb = __builtin_amdgcn_ballot_w64(B != 0u);
+        acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (uint32_t)bb, B, 0xF6);  // acc | (b ^ B)
+        acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (uint32_t)(bb >> 32), B, 0xF6);
+    }
+    row[448 + lane] = __builtin_amdgcn_mbcnt_hi(~acc_hi, __builtin_amdgcn_mbcnt_lo(~acc_lo, 0u));
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void lds_atomic_order_probe(uint32_t seed, uint32_t iters, uint32_t* failures) {
     __shared__ uint32_t s_cnt[8][RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

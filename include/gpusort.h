@@ -101,9 +101,8 @@ typedef struct gs_onesweep_options {
                                         keys turn out near-uniform, the four LSD passes otherwise; 1 LSD passes only; 2 two-level plan wherever it can run */
     int32_t first_pass_big;          /* 1 (default): keys-only mid sizes run their first pass on the 16 384-key tile */
     uint32_t hist_blocks;            /* workgroups of the GlobalHistogram kernel; 0 (default) = one per CU (tuning aid) */
-    uint32_t debug_flags;            /* 0.  Product build: bit 30 only (bring-up aid, tools/hy_bringup.py: the two-level plan stops behind its second
-                                        pass); every other bit is masked off.  Tuning / experiment builds: bits 0-2 shape of the bucket-local sort,
-                                        bits 8-17 the round-4 local-sort plan's switches, GS_EXP builds: bits 8-11 ablation modes */
+    uint32_t debug_flags;            /* 0.  The product build ignores every bit.  Tuning / experiment builds (-DGS_TUNING, -DGS_EXP): bit 30 = the two-level
+                                        plan stops behind its second pass (tools/hy_bringup.py; the result is NOT sorted), GS_EXP builds: bits 8-11 ablation modes */
 } gs_onesweep_options;
 void gs_onesweep_options_default(gs_onesweep_options* o);
 /* gs_onesweep_create with explicit options (NULL = defaults).  GS_ERR_ARG for a struct_size this library does not know, a tile
@@ -187,8 +186,9 @@ gs_status gs_onesweep_set_skip_passes(gs_onesweep* h, int on);
  * 16 bits); whether they do is decided ON THE DEVICE from the histogram (no host round trip): otherwise the same launches run the
  * four LSD passes on position chains.
  *   0 (default): the two-level plan is offered from 3 x 2^24 (50 M) keys up, to pairs from 2^25 + 1 (measured crossovers);  1: never (the
- *   LSD passes only);  2 (tests): offered at every size from gs_onesweep_options::position_chains_min_log2 up.  GS_ERR_MODE for 2 on a
- *   handle without the plan's tables (max_keys <= 2^20, or created with plan 1).  Pairs: the values travel with their keys through
+ *   LSD passes only);  2 (tests): offered at every size from gs_onesweep_options::position_chains_min_log2 up.  A handle that was
+ *   created without the plan's tables (below the plan's default size, or with plan 1) gets them allocated by gs_onesweep_set_plan(h, 2)
+ *   — call it with no sort of the handle in flight; GS_ERR_MODE for max_keys <= 2^20 (neither the plan nor its fall-back runs there).  Pairs: the values travel with their keys through
  *   both DigitBinningPasses and are moved once more by the bucket-local sort — 52 / 76 bytes per pair instead of 68 / 100.
  * gs_onesweep_last_plan (synchronous) reports what the device decided for the last sort: *plan = 1 the two-level plan ran, 0 the LSD
  * passes (or a one- / two-launch route); *largest_bucket (may be NULL) = the largest 16-bit-prefix bucket it saw (0 if not offered). */
@@ -197,6 +197,11 @@ gs_status gs_onesweep_last_plan(gs_onesweep* h, uint32_t* plan, uint32_t* larges
 /* Device probe: do same-address lanes of one LDS atomic get their results in
  * ascending lane order?  Synchronous; *h_failures = mismatching lanes. */
 gs_status gs_selftest_lds_atomic_order(uint32_t iters, uint32_t seed, uint64_t* h_failures, void* stream);
+/* Self-test of the wave-level primitives (wave64 scans by shuffle and by DPP, reduction, 64-bit ballot, mbcnt lane rank, the
+ * eight-ballot multi-split) — what the reference builds from PTX and 32-lane *_sync intrinsics in GPUSortingCUDA/Utils.cuh:22-126 and
+ * OneSweep.cu:207-253.  Enqueues one kernel: `waves` (a multiple of 4) waves each write 8 rows of 64 words to d_out
+ * (waves x 512 uint32); row layout and the input word of a lane: onesweep_kernels.hpp, wave_primitives_kernel.  The caller compares. */
+gs_status gs_selftest_wave_primitives(uint32_t seed, uint32_t waves, uint32_t* d_out, void* stream);
 /* Instrumented builds only (-DGS_EXP=2, tools/trace_tiles.py): device buffer of 4 passes x grid x 8 words that
  * receives per-tile phase timestamps.  A no-op in the product build. */
 gs_status gs_debug_set_trace(gs_onesweep* h, void* d_buf);

@@ -835,3 +835,39 @@ def test_scan_state_invariants(gpu, oracle):
         s.global_histogram(dk)
         assert s.check_state()["hist_words_nonzero"] == 0
         s.close()
+
+
+def test_wave_primitives_against_the_host(gpu):
+    """the wave-level primitives (the wave64 counterparts of GPUSortingCUDA/Utils.cuh:22-126 and of the ballot
+    multi-split of OneSweep.cu:207-253) checked on their own, lane by lane, against numpy: inclusive scans (shuffle form and DPP form),
+    reduction, the 64-bit ballot, mbcnt as the lanemask_lt popcount, and the rank of a lane among the lanes holding its digit."""
+    import torch
+    from gpusorting_amd import _lib
+    waves, seed = 64, 20260930
+    out = torch.zeros(waves * 512, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().gs_selftest_wave_primitives(seed, waves, out.data_ptr(), int(torch.cuda.current_stream().cuda_stream)), "selftest")
+    torch.cuda.synchronize()
+    r = out.cpu().numpy().view(np.uint32).reshape(waves, 8, 64)
+    i = np.arange(waves * 64, dtype=np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    h = ((np.uint64(seed) ^ ((i * np.uint64(2654435761)) & M)) * np.uint64(2246822519)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(3266489917)) & M
+    x = (h ^ (h >> np.uint64(16))).astype(np.uint32).reshape(waves, 64)
+    np.testing.assert_array_equal(r[:, 0], x)
+    lo = (x & 0xFFFF).astype(np.uint64)
+    incl = np.cumsum(lo, axis=1).astype(np.uint32)
+    np.testing.assert_array_equal(r[:, 1], incl)                       # wave_inclusive_scan (shuffles)
+    np.testing.assert_array_equal(r[:, 2], incl)                       # wave_inclusive_scan_dpp
+    np.testing.assert_array_equal(r[:, 3], np.repeat(incl[:, 63:64], 64, axis=1))   # wave_reduce_sum, lane 0's value broadcast
+    bit = (x & 1).astype(np.uint64)
+    ballot = (bit << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1)
+    np.testing.assert_array_equal(r[:, 4], np.repeat((ballot & M).astype(np.uint32)[:, None], 64, axis=1))
+    np.testing.assert_array_equal(r[:, 5], np.repeat((ballot >> np.uint64(32)).astype(np.uint32)[:, None], 64, axis=1))
+    below = (np.cumsum(bit, axis=1) - bit).astype(np.uint32)           # set lanes below this lane
+    np.testing.assert_array_equal(r[:, 6], below)
+    d = x & 0xFF
+    rank = np.zeros_like(d)
+    for l in range(64):
+        rank[:, l] = (d[:, :l] == d[:, l:l + 1]).sum(axis=1)
+    np.testing.assert_array_equal(r[:, 7], rank)                       # the multi-split's rank among equal digits
