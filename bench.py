@@ -767,6 +767,9 @@ def main():
             "xgmi_link_peak_GBps": link_peak, "links_used_per_rank": world - 1,
             "frac_of_link_peak": per_rank_gbs / max(world - 1, 1) / link_peak,
             "split": sharded.last_split,
+            "bucket_layout": ("bin-major in the local sort's alternate buffer (one message per (peer, top byte)): the local sort starts at the two-level "
+                              "plan's second pass — the sender's split pass was its first") if getattr(sharded, "last_bin_major", False) else
+                             "source-major in the output buffer: full local sort",
             "exchange_call_ab": exchange_ab,
         }
 

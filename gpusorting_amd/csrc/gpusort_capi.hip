@@ -363,7 +363,7 @@ struct PassPlan {
 // of the ordinary one, and both plans' launches follow (sort_impl)
 gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type kt, hipStream_t s, uint32_t p0,
                    uint32_t np, PassPlan* plan, uint32_t scan_plan = 0, int shape_index = -1, uint32_t word = 0, int shape0_index = -1,
-                   uint32_t pos_tile = POS_TILE, bool hy = false) {
+                   uint32_t pos_tile = POS_TILE, bool hy = false, bool pregrouped = false) {
     h->msd_keys = nullptr;  // whatever an earlier gs_onesweep_msd_prepare left in the slab is overwritten now
     h->last_hy = hy ? 1 : 0;
     const Shape& sh = g_shapes[shape_index < 0 ? h->shape : shape_index];
@@ -402,7 +402,7 @@ gs_status prologue(gs_onesweep* h, const void* d_keys, uint32_t n, gs_key_type k
         g_hy_hist[kt](s, G, static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, per_wg, wg_per_seg, h->partials, g_hy_class[hy_class(n)].cap);
         hipLaunchKernelGGL(gs::hy_reduce_kernel, dim3(gs::RADIX + gs::NCH), dim3(256), 0, s, h->partials, G, wg_per_seg, h->hy_tab, h->slab + SLAB_HIST);
         if (rec) GS_HIP(hipEventRecord(h->ev[2], s));
-        hipLaunchKernelGGL(gs::hy_scan_kernel, dim3(1), dim3(1024), 0, s, h->slab, h->hy_tab, n, seg_len0, desc_stride, g_hy_class[hy_class(n)].cap, tile);
+        hipLaunchKernelGGL(gs::hy_scan_kernel, dim3(1), dim3(1024), 0, s, h->slab, h->hy_tab, n, seg_len0, desc_stride, g_hy_class[hy_class(n)].cap, tile, pregrouped ? 1u : 0u);
     } else {
     g_hist[kt](s, hist_blocks(n, h->hist_blocks_opt), static_cast<const uint32_t*>(d_keys), h->slab, used_words, n, seg_len0, p0, np, word,
                (scan_plan & 4u) ? (h->pos_chains == 2 ? 3u : 1u) : 0u, h->partials);
@@ -513,20 +513,72 @@ inline int mid_class(uint32_t n, uint32_t vb) {
     return -1;
 }
 
-// values_ready (multi-GPU): an event behind which d_vals is complete — the keys already are, so GlobalHistogram + Scan (which read
-// keys only) run before the stream waits for it; the one- and two-launch routes wait first.
-gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
-                    gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb, hipEvent_t values_ready = nullptr) {
+// Which way a sort of n elements goes — decided on the host from sizes, modes and options alone (what the KEYS look like is the
+// device's business: identity passes, skew, the two-level plan's validity).  sort_impl enqueues accordingly; gs_onesweep_sort_sharded
+// asks whether a bucket it is about to receive will be offered the two-level plan (`hy`) before it chooses the exchange's layout.
+struct SortRoute {
+    SmallLauncher small;  // != nullptr: one workgroup, one launch
+    int mid_cls;          // >= 0: the two-launch mid-size route (mid_kernels.hpp), class index
+    int shape, shape0;    // tile shapes of the general pipeline: passes 1.., first pass
+    uint32_t dyn;         // 2: the Scan kernel plans the passes on the device (identity passes dropped, source buffers); 0: fixed ping-pong
+    bool pos;             // the sort may be planned on position chains (PF_POS): every pass is launched in both chain forms
+    bool hy;              // the sort is offered the two-level plan (hybrid_kernels.hpp): both plans' launches are enqueued
+};
+SortRoute sort_route(const gs_onesweep* h, uint32_t n, gs_key_type kt, uint32_t vb) {
+    SortRoute r{};
     // routing by size: one workgroup up to 8192 keys; two launches (MSD pass + bucket sorts) up to 2^20 (2^22 pairs with 4-byte
     // values, 2^23 keys-only: mid_class); the general pipeline above.  (The 16 384- and 32 768-slot single-tile kernels serve when the mid-size route is switched off:
     // with it, 2^15 keys take 18 us instead of 34, profiles/r02_size_and_entropy_sweep.txt.)
-    const int mid_cls = (h->mid_path && h->shape_auto && n > gs::SMALL_TILE && !is_key64(kt)) ? mid_class(n, vb) : -1;
+    r.mid_cls = (h->mid_path && h->shape_auto && n > gs::SMALL_TILE && !is_key64(kt)) ? mid_class(n, vb) : -1;
 #ifdef GS_MINIMAL
-    const bool use_mid = false;
-#else
-    const bool use_mid = mid_cls >= 0;
+    r.mid_cls = -1;
 #endif
-    if (SmallLauncher small = (h->small_path && !use_mid) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr) {
+    r.small = (h->small_path && r.mid_cls < 0) ? small_launcher(n, h->rank_mode, vb, kt) : nullptr;
+    // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
+    // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
+    const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys;
+    r.shape = (h->shape_auto && n <= mid_keys(vb) && !pos_size) ? MID_SHAPE : h->shape;
+    if (is_key64(kt) && !g_shapes[r.shape].fn[h->rank_mode][vb_index(vb)][kt]) r.shape = MID_SHAPE;
+    const Shape& sh = g_shapes[r.shape];
+    // Mid sizes, keys-only (2^22 < n <= 2^25: the 8192-key tile): the FIRST pass runs on the 16 384-key tile.  Its position segments are
+    // whole tiles (prologue), so 2^24 keys are exactly 1024 tiles — two launch rounds on the 512 slots of that shape instead of three
+    // rounds of 8192-key tiles on 768 — and its input is cold, which the larger tile streams better; the later passes' chains are
+    // digit groups with a partial tile at each end, which overflow the round.  gs_onesweep_options::first_pass_big = 0 switches it off (A/B).
+    r.shape0 = (h->first_pass_big && h->shape_auto && r.shape == MID_SHAPE && vb == 0 && !is_key64(kt) && n > (1u << 22) &&
+                g_shapes[0].fn[h->rank_mode][0][kt] != nullptr) ? 0 : r.shape;
+    // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
+    // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
+    r.dyn = h->skip_passes ? 2u : 0u;
+    // The sort may run on position chains in every pass (PF_POS; decided on the device: the histogram kernel finds the
+    // digit groups uneven, the Scan kernel plans accordingly) — every pass is then launched in both chain forms and the
+    // plan says which one works.  Sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; gs_onesweep_options::position_chains = 0
+    // switches it off.
+    r.pos = r.dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
+            (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
+            (vb == 4 ? sh.threads * sh.kpt == 16384 : (sh.threads == 512 && sh.kpt == 32));  // (the plan's last pass runs on 16 384-key tiles)
+    // Two-level plan (hybrid_kernels.hpp): sorts of 32-bit keys — keys-only and pairs with 4- / 8-byte values — that may also run on
+    // position chains (its fall-back when the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
+    // (position_chains = 2 asks for the position-chain plan whatever the keys look like: only plan 2 overrides that)
+    r.hy = r.pos && !r.small && r.mid_cls < 0 && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
+           (h->plan == 2 || (n >= (vb ? HY_MIN_PAIRS_DEFAULT : h->hy_min_keys) && h->pos_chains != 2)) &&
+           (vb == 0 || (g_persist[vb == 8][kt] != nullptr && g_hy_local_pairs[vb == 8][hy_class(n)][kt] != nullptr)) &&
+           (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, pos_tile_for(vb) & 0x7fffffffu) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;  // (prologue's row formula)
+    return r;
+}
+
+// values_ready (multi-GPU): an event behind which d_vals is complete — the keys already are, so GlobalHistogram + Scan (which read
+// keys only) run before the stream waits for it; the one- and two-launch routes wait first.
+gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys, void* d_alt_vals, uint32_t n,
+                    gs_key_type kt, gs_order order, hipStream_t s, uint32_t vb, hipEvent_t values_ready = nullptr, bool pregrouped = false) {
+    // pregrouped (multi-GPU, gs_onesweep_sort_sharded): the input lies in the ALTERNATE buffers, already grouped by its top byte in
+    // ascending order — the bucket exchange landed it bin by bin — and the caller made sure (hy_offered) that the sort is offered the
+    // two-level plan: its pass A (the top-byte partition) is skipped, pass B reads the alternate buffers as it always does.  If the device
+    // finds the plan void, hy_void_copy_kernel moves the input to the caller's buffers and the four LSD passes run as ever.
+    const SortRoute route = sort_route(h, n, kt, vb);
+    if (pregrouped && !route.hy) return GS_ERR_ARG;  // (the caller asks sort_route first)
+    const int mid_cls = route.mid_cls;
+    const bool use_mid = mid_cls >= 0;
+    if (SmallLauncher small = route.small) {
         if (values_ready) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));
         if (h->profiling) GS_HIP(hipEventRecord(h->ev[0], s));
         small(s, static_cast<uint32_t*>(d_keys), d_vals, n, order == GS_ORDER_DESCENDING ? 1u : 0u, h->slab + SLAB_STATUS);
@@ -556,39 +608,13 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
         return GS_OK;
     }
 #endif
-    // 64-bit keys: 8-byte stage slots fit 8192-key tiles only (the mid-size shape), at every size
-    // (a sort that may be planned on position chains — see `pos` below — runs on the default tile: the dual kernel's shapes)
-    const bool pos_size = h->skip_passes && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 &&
-                          n >= h->pos_min_keys;
-    int shape = (h->shape_auto && n <= mid_keys(vb) && !pos_size) ? MID_SHAPE : h->shape;
-    if (is_key64(kt) && !g_shapes[shape].fn[h->rank_mode][vb_index(vb)][kt]) shape = MID_SHAPE;
+    const int shape = route.shape, shape0 = route.shape0;
     const Shape& sh = g_shapes[shape];
     BinLauncher fn = sh.fn[h->rank_mode][vb_index(vb)][kt];
     if (!fn) return GS_ERR_ARG;
-    // Mid sizes, keys-only (2^22 < n <= 2^25: the 8192-key tile): the FIRST pass runs on the 16 384-key tile.  Its position segments are
-    // whole tiles (prologue), so 2^24 keys are exactly 1024 tiles — two launch rounds on the 512 slots of that shape instead of three
-    // rounds of 8192-key tiles on 768 — and its input is cold, which the larger tile streams better; the later passes' chains are
-    // digit groups with a partial tile at each end, which overflow the round.  gs_onesweep_options::first_pass_big = 0 switches it off (A/B).
-    const int shape0 = (h->first_pass_big && h->shape_auto && shape == MID_SHAPE && vb == 0 && !is_key64(kt) && n > (1u << 22) &&
-                        g_shapes[0].fn[h->rank_mode][0][kt] != nullptr) ? 0 : shape;
     BinLauncher fn0 = g_shapes[shape0].fn[h->rank_mode][vb_index(vb)][kt];
-    // The scan kernel decides on the device which passes run and which buffer each one reads (identity passes
-    // are dropped in pairs, see scan_kernel); every pass is handed (keys, alt) and the sort's order.
-    const uint32_t dyn = h->skip_passes ? 2u : 0u;
-    // bit 2: the sort may run on position chains in every pass (PF_POS; decided on the device: the histogram kernel finds the
-    // digit groups uneven, the Scan kernel plans accordingly) — every pass is then launched in both chain forms and the
-    // plan says which one works.  Keys-only sorts of 32-bit keys on the big tile shape, LDS-atomic ranking; gs_onesweep_options::position_chains = 0
-    // switches it off.
-    const bool pos = dyn && h->rank_mode == 1 && !is_key64(kt) && h->pos_chains != 0 && n >= h->pos_min_keys &&
-                     (vb == 0 ? g_dual[0][kt] : g_posv[vb == 8][0][kt]) != nullptr &&
-                     (vb == 4 ? sh.threads * sh.kpt == 16384 : (sh.threads == 512 && sh.kpt == 32));  // (the plan's last pass runs on 16 384-key tiles)
-    // Two-level plan (hybrid_kernels.hpp): sorts of 32-bit keys — keys-only and pairs with 4- / 8-byte values — that may also run on
-    // position chains (its fall-back when the keys turn out skewed) — the histogram sweep counts the 16-bit prefixes, and the device decides which plan runs.
-    // (position_chains = 2 asks for the position-chain plan whatever the keys look like: only plan 2 overrides that)
-    const bool hy = pos && h->hy_tab != nullptr && g_hy_hist[kt] != nullptr && h->plan != 1 &&
-                    (h->plan == 2 || (n >= (vb ? HY_MIN_PAIRS_DEFAULT : h->hy_min_keys) && h->pos_chains != 2)) &&
-                    (vb == 0 || (g_persist[vb == 8][kt] != nullptr && g_hy_local_pairs[vb == 8][hy_class(n)][kt] != nullptr)) &&
-                    (size_t)gs::SLAB_DESC + 4 * (size_t)(div_up(n, pos_tile_for(vb) & 0x7fffffffu) + 2 * gs::CHMAX + 8) * gs::RADIX <= h->slab_words;  // (prologue's row formula)
+    const uint32_t dyn = route.dyn;
+    const bool pos = route.pos, hy = route.hy;
     uint32_t* k[2] = {static_cast<uint32_t*>(d_keys), static_cast<uint32_t*>(d_alt_keys)};
     void* v[2] = {d_vals, d_alt_vals};
     // 64-bit keys: ONE GlobalHistogram + Scan plans all eight passes (eight joint tables from one sweep over the keys; the
@@ -609,9 +635,19 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
     for (uint32_t word = 0; word < rounds; ++word) {
         const uint32_t desc_bit = (order == GS_ORDER_DESCENDING && word + 1 == rounds) ? 1u : 0u;
         PassPlan plan;
-        gs_status st = prologue(h, d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0, pos_tile_for(vb), hy);
+        gs_status st = prologue(h, pregrouped ? d_alt_keys : d_keys, n, kt, s, 0, NP, &plan, desc_bit | dyn | (pos ? 4u : 0u), shape, word, shape0, pos_tile_for(vb), hy, pregrouped);
         if (st != GS_OK) return st;
         if (values_ready && word == 0) GS_HIP(hipStreamWaitEvent(s, values_ready, 0));  // histogram + scan ran on the keys meanwhile
+        if (pregrouped) {  // the plan may turn out void: the LSD passes read the caller's buffers (exits at once otherwise)
+            const size_t kw = (size_t)n;  // key words
+            hipLaunchKernelGGL(gs::hy_void_copy_kernel, dim3(pos_grid()), dim3(256), 0, s, h->slab, static_cast<const uint4*>(d_alt_keys), static_cast<uint4*>(d_keys),
+                               kw / 4, static_cast<const uint32_t*>(d_alt_keys) + (kw & ~(size_t)3), static_cast<uint32_t*>(d_keys) + (kw & ~(size_t)3), (uint32_t)(kw & 3));
+            if (vb) {
+                const size_t vw = (size_t)n * (vb / 4);
+                hipLaunchKernelGGL(gs::hy_void_copy_kernel, dim3(pos_grid()), dim3(256), 0, s, h->slab, static_cast<const uint4*>(d_alt_vals), static_cast<uint4*>(d_vals),
+                                   vw / 4, static_cast<const uint32_t*>(d_alt_vals) + (vw & ~(size_t)3), static_cast<uint32_t*>(d_vals) + (vw & ~(size_t)3), (uint32_t)(vw & 3));
+            }
+        }
         for (uint32_t p = 0; p < NP; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
             const uint32_t mode = (dyn ? (desc_bit | gs::BM_PLANNED) : ((desc_bit && p == NP - 1) ? gs::BM_REVERSE : 0u)) | (p == 0 ? gs::BM_ZERO_HIST : 0u);

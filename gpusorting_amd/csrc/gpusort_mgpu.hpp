@@ -10,12 +10,19 @@
 //   3. msd_plan_kernel: splitters, per-peer send/receive counts, overflow check — on the device
 //   4. ONE small device-to-host copy (the plan: a few dozen words) and ONE event wait: RCCL's send/recv take their
 //      counts as host integers, so this wait is inherent in the exchange, and it is the only one
-//   5. the stable DigitBinningPass on the top byte groups the shard by destination (reusing the scan state of 1)
+//   5. the stable DigitBinningPass on the top byte groups the shard by destination (reusing the scan state of 1) — and, inside a
+//      destination, by top byte: this IS the first pass of the receiver's two-level sort (hybrid_kernels.hpp, pass A)
 //   6. bucket exchange: grouped ncclSend / ncclRecv pairs — point-to-point on all xGMI links at once.  Pairs: the KEYS go
 //      first, on the caller's stream; the VALUES follow on a second communicator (ncclCommSplit) and a second stream, so
-//      that
-//   7. the local 4-pass OneSweep of the received bucket starts on the keys (GlobalHistogram + Scan read nothing else)
-//      while the values are still on the links; its first pass waits for them
+//      that step 7 starts on the keys while the values are still on the links.  Round 6: ONE MESSAGE PER (peer, top byte) — all
+//      of a call's messages inside one ncclGroup — so that the receiver chooses where each (source, top byte) segment lands: a
+//      bucket that will be offered the two-level plan is landed BIN-MAJOR (top byte, then source rank, then the source's order:
+//      exactly the stable order of a top-byte partition of the concatenated sources) in the local sort's alternate buffer,
+//   7. and the local sort of the received bucket starts at pass B (sort_impl's `pregrouped`): histogram sweep + Scan, the
+//      DigitBinningPass on byte 2, the bucket-local sort — 20 B/key instead of 28: round 5 did the top-byte partition twice, once
+//      per side of the exchange.  Buckets below the plan's size, the 12-bit split and ncclAllToAllv (one buffer pair per call)
+//      keep the source-major layout and the full local sort; a bucket whose keys void the plan on the device (skew) is copied to
+//      the caller's buffer by hy_void_copy_kernel and takes the four LSD passes
 //   8. a one-word all-gather of every rank's status closes the call (see FAILURES)
 // Why grouped send/recv and not ncclAllToAllv (rccl.h:815, the call BASELINE.json names): RCCL implements AllToAllv as
 // exactly this group of sends and receives, but through one entry point that takes ONE buffer pair — keys and values
@@ -178,6 +185,8 @@ struct gs_mgpu {
     void* part_vals;
     uint32_t *d_hist, *d_table, *d_plan;  // nbins, world x nbins, plan words
     uint32_t* h_plan;          // pinned mirror of the plan
+    uint32_t* h_table;         // pinned mirror of the gathered [source][top byte] table (world x 256): the exchange goes bin by bin
+    uint32_t last_pregrouped;  // the last call landed its bucket bin-major and its local sort skipped the top-byte pass
     hipEvent_t ev_plan, ev[5];
     int force_exchange;        // run split + exchange even with one rank (tests)
     float last_ms[4];
@@ -196,6 +205,7 @@ gs_status mgpu_alloc(gs_mgpu* c) {
     GS_HIP(hipMalloc(&c->d_table, (size_t)c->world * 4096 * sizeof(uint32_t)));
     GS_HIP(hipMalloc(&c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t)));
     GS_HIP(hipHostMalloc(&c->h_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipHostMallocDefault));
+    GS_HIP(hipHostMalloc(&c->h_table, (size_t)c->world * gs::RADIX * sizeof(uint32_t), hipHostMallocDefault));
     GS_HIP(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
     for (auto& e : c->ev) GS_HIP(hipEventCreate(&e));
     GS_HIP(hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking));
@@ -261,6 +271,7 @@ gs_status mgpu_plan(gs_mgpu* c, const void* d_keys, uint32_t n, gs_key_type kt, 
     if (c->transport.all_gather_u32(c->transport.user, c->d_hist, c->d_table, nbins, s) != 0) return GS_ERR_COMM;
     hipLaunchKernelGGL(gs::msd_plan_kernel, dim3(1), dim3(256), 0, s, c->d_table, nbins, c->world, c->rank, c->capacity, c->d_plan);
     GS_HIP(hipMemcpyAsync(c->h_plan, c->d_plan, gs::plan_words(c->world) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!fine) GS_HIP(hipMemcpyAsync(c->h_table, c->d_table, (size_t)c->world * gs::RADIX * sizeof(uint32_t), hipMemcpyDeviceToHost, s));  // 8 KiB at world 8
     GS_HIP(hipEventRecord(c->ev_plan, s));
     GS_HIP(hipEventSynchronize(c->ev_plan));  // the ONE host wait of the pipeline: send/recv counts are host integers
     return GS_OK;
@@ -381,6 +392,7 @@ gs_status gs_mgpu_destroy(gs_mgpu* c) {
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->h_plan) (void)hipHostFree(c->h_plan);
+    if (c->h_table) (void)hipHostFree(c->h_table);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -418,6 +430,7 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
     c->call_complete = false;  // until this call's closing gather is behind us: the status words on the device are an EARLIER call's
     c->last_sent = c->last_recv = 0;
     c->last_fine = 0;
+    c->last_pregrouped = 0;
     GS_HIP(hipEventRecord(c->ev[0], s));
     uint32_t n_recv = n;
     hipEvent_t values_ready = nullptr;  // pairs with the values on the second stream: the local sort's passes wait for it
@@ -461,14 +474,24 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         // ---- from here on the peers are committed to the exchange: an error of this rank is carried through it ----
         if (c->debug_fail == 2) local = GS_ERR_HIP;  // test hook: as if the partition pass had failed to launch
         c->debug_fail = 0;
+        // Layout of the received bucket (this rank's own decision): bin-major in the local sort's ALTERNATE buffer if that sort will be
+        // offered the two-level plan — its top-byte pass is then behind us — source-major in the caller's buffer otherwise.
+        // Messages per (peer, top byte): whenever the exchange can carry them (not the 12-bit split, not ncclAllToAllv).
+        const bool by_bin = !fine && !(c->owns_comm && c->alltoallv);
+        const bool pre = by_bin && n_recv != 0 && sort_route(h, n_recv, kt, vb).hy;
+        c->last_pregrouped = pre ? 1u : 0u;
+        uint32_t* const split_keys = pre ? static_cast<uint32_t*>(d_out_keys) : c->part_keys;  // where the shard is grouped = the send buffer
+        void* const split_vals = pre ? d_out_vals : c->part_vals;
+        uint32_t* const land_keys = pre ? c->part_keys : static_cast<uint32_t*>(d_out_keys);    // where the bucket lands
+        void* const land_vals = pre ? c->part_vals : d_out_vals;
         // group the shard by destination (stable)
         if (n && local == GS_OK) {
             const BinLauncher fn = g_shapes[h->shape].fn[h->rank_mode][vb_index(vb)][kt];
             if (!fn) {
                 local = GS_ERR_ARG;
             } else if (!fine) {
-                fn(s, pp.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys)), c->part_keys, const_cast<void*>(d_vals),
-                   c->part_vals, h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB,
+                fn(s, pp.grid, const_cast<uint32_t*>(static_cast<const uint32_t*>(d_keys)), split_keys, const_cast<void*>(d_vals),
+                   split_vals, h->slab + SLAB_DESC, h->slab + SLAB_COUNTERS, h->slab + SLAB_INFO, h->slab + gs::SLAB_HSUB,
                    h->slab + SLAB_STATUS, n, 24, gs::BM_ZERO_HIST);
                 if (hipGetLastError() != hipSuccess) local = GS_ERR_HIP;
                 h->hist_dirty = false;
@@ -490,19 +513,63 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
             a += send[p]; b += recv[p];
             if (p != c->rank) { c->last_sent += (uint64_t)send[p] * (4 + vb); c->last_recv += (uint64_t)recv[p] * (4 + vb); }
         }
-        const void* src[2] = {c->part_keys, c->part_vals};
-        void* dst[2] = {d_out_keys, d_out_vals};
+        // Rounds: round j carries, for every peer p, top byte first[p] + j of p's range (ONE round with whole buckets if the exchange
+        // goes peer by peer, or with one rank: a single source is bin-major as it is).  Both sides derive every count from the same
+        // gathered table; messages between two ranks are matched in the order they are issued, bin by bin.
+        const uint32_t* first = recv + W;              // first_bin[world + 1]
+        const uint32_t* T = c->h_table;                // [source][top byte]
+        const bool rounds_by_bin = by_bin && W > 1;
+        uint32_t R = 1;
+        std::vector<uint32_t> L, D;                    // start of bin b in my grouped shard; landing place of (source q, my bin j)
+        if (rounds_by_bin) {
+            R = 0;
+            for (uint32_t p = 0; p < W; ++p) R = first[p + 1] - first[p] > R ? first[p + 1] - first[p] : R;
+            L.assign(gs::RADIX + 1, 0);
+            for (uint32_t x = 0; x < gs::RADIX; ++x) L[x + 1] = L[x] + T[(size_t)c->rank * gs::RADIX + x];
+            const uint32_t f0 = first[c->rank], nb = first[c->rank + 1] - f0;
+            D.assign((size_t)W * (nb ? nb : 1), 0);
+            uint32_t run = 0;
+            if (pre) { for (uint32_t j = 0; j < nb; ++j) for (uint32_t q = 0; q < W; ++q) { D[(size_t)q * nb + j] = run; run += T[(size_t)q * gs::RADIX + f0 + j]; } }
+            else     { for (uint32_t q = 0; q < W; ++q) for (uint32_t j = 0; j < nb; ++j) { D[(size_t)q * nb + j] = run; run += T[(size_t)q * gs::RADIX + f0 + j]; } }
+        }
+        std::vector<uint32_t> sc(W), sdp(W), rc(W), rdp(W);
+        auto round_counts = [&](uint32_t j) {
+            const uint32_t f0 = first[c->rank], nb = first[c->rank + 1] - f0;
+            for (uint32_t p = 0; p < W; ++p) {
+                const uint32_t bp = first[p] + j;      // the byte of p's range this round carries
+                const bool sends = bp < first[p + 1];
+                sc[p] = sends ? T[(size_t)c->rank * gs::RADIX + bp] : 0u;
+                sdp[p] = sends ? L[bp] : 0u;
+                rc[p] = j < nb ? T[(size_t)p * gs::RADIX + f0 + j] : 0u;
+                rdp[p] = j < nb ? D[(size_t)p * nb + j] : 0u;
+            }
+        };
+        // all rounds of one array set in ONE ncclGroup (nested groups merge): one launch, every link busy from the start
+        auto exchange_all = [&](const gs_mgpu_transport& t, uint32_t n_arrays, const void* const* src_, void* const* dst_, const uint32_t* eb_, hipStream_t st_) -> int {
+            if (!rounds_by_bin) return t.exchange(t.user, n_arrays, src_, dst_, eb_, send, sd.data(), recv, rd.data(), st_);
+            const bool grouped = c->owns_comm && rccl() != nullptr;
+            int e = grouped ? rccl()->GroupStart() : 0;
+            for (uint32_t j = 0; j < R && !e; ++j) {
+                round_counts(j);
+                e = t.exchange(t.user, n_arrays, src_, dst_, eb_, sc.data(), sdp.data(), rc.data(), rdp.data(), st_);
+            }
+            const int e2 = grouped ? rccl()->GroupEnd() : 0;
+            if (grouped && (e || e2)) g_last_rccl_error = e ? e : e2;
+            return e ? e : e2;
+        };
+        const void* src[2] = {split_keys, split_vals};
+        void* dst[2] = {land_keys, land_vals};
         const uint32_t eb[2] = {4u, vb};
         hipStream_t tail = s;  // the stream the closing status gather goes on
         if (vb && c->overlap) {
             // keys on the caller's stream; values on the second stream (and the second communicator) behind the partition pass
             if (hipEventRecord(c->ev_part, s) != hipSuccess || hipStreamWaitEvent(c->s2, c->ev_part, 0) != hipSuccess) note(GS_ERR_HIP);
-            if (c->transport.exchange(c->transport.user, 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) note(GS_ERR_COMM);
-            if (c->transport2.exchange(c->transport2.user, 1u, src + 1, dst + 1, eb + 1, send, sd.data(), recv, rd.data(), c->s2) != 0) note(GS_ERR_COMM);
+            if (exchange_all(c->transport, 1u, src, dst, eb, s) != 0) note(GS_ERR_COMM);
+            if (exchange_all(c->transport2, 1u, src + 1, dst + 1, eb + 1, c->s2) != 0) note(GS_ERR_COMM);
             if (hipEventRecord(c->ev_vals, c->s2) != hipSuccess) note(GS_ERR_HIP);
             values_ready = c->ev_vals;
             tail = c->s2;
-        } else if (c->transport.exchange(c->transport.user, vb ? 2u : 1u, src, dst, eb, send, sd.data(), recv, rd.data(), s) != 0) {
+        } else if (exchange_all(c->transport, vb ? 2u : 1u, src, dst, eb, s) != 0) {
             note(GS_ERR_COMM);
         }
         if (hipEventRecord(c->ev[2], s) != hipSuccess) note(GS_ERR_HIP);
@@ -523,10 +590,12 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
             return local;
         }
     }
-    // local 4-pass sort of the received bucket; the partition buffers are free again and serve as alt
+    // local sort of the received bucket; the partition buffers are free again and serve as alt.  A bucket that was landed bin-major
+    // in the alternate buffer (c->last_pregrouped) starts at the two-level plan's second pass.
     if (n_recv) {
-        gs_status st = vb ? sort_impl(h, d_out_keys, d_out_vals, c->part_keys, c->part_vals, n_recv, kt, GS_ORDER_ASCENDING, s, vb, values_ready)
-                          : gs_onesweep_sort_keys(h, d_out_keys, c->part_keys, n_recv, kt, GS_ORDER_ASCENDING, s);
+        gs_status st = (vb || c->last_pregrouped)
+                           ? sort_impl(h, d_out_keys, d_out_vals, c->part_keys, c->part_vals, n_recv, kt, GS_ORDER_ASCENDING, s, vb, values_ready, c->last_pregrouped != 0)
+                           : gs_onesweep_sort_keys(h, d_out_keys, c->part_keys, n_recv, kt, GS_ORDER_ASCENDING, s);
         if (st != GS_OK) { c->failed = 1; return st; }
     } else if (values_ready) {
         GS_HIP(hipStreamWaitEvent(s, values_ready, 0));
@@ -573,6 +642,12 @@ gs_status gs_mgpu_get_profile(gs_mgpu* c, float ms[4], uint64_t* bytes_sent, uin
     if (bytes_sent) *bytes_sent = c->last_sent;
     if (bytes_received) *bytes_received = c->last_recv;
     if (fine_split) *fine_split = c->last_fine;
+    return GS_OK;
+}
+
+gs_status gs_mgpu_last_layout(gs_mgpu* c, uint32_t* bin_major) {
+    if (!c || !bin_major) return GS_ERR_ARG;
+    *bin_major = c->last_pregrouped;  // (host state of the last call: no synchronisation)
     return GS_OK;
 }
 

@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void hy_reduce_kernel(const uint32_t* __restri
 //   plan_bits bit 0: descending (pass B applies the reversal: it is the plan's last DigitBinningPass; hy_local_sort_kernel mirrors)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t* tab, uint32_t n, uint32_t seg_len0, uint32_t desc_stride,
-                                                        uint32_t cap, uint32_t tile) {
+                                                        uint32_t cap, uint32_t tile, uint32_t pregrouped /*the input is already grouped by
+                                                        its top byte and lies in the ALTERNATE buffer (multi-GPU: the bucket exchange landed it
+                                                        there bin by bin): pass A has nothing to do*/) {
     // Row i (16 rows) = prefixes [4096 i, 4096 (i + 1)); thread t holds prefixes 4096 i + 4 t .. + 3 of every row: all global
     // accesses are coalesced 16-byte ones (64 consecutive prefixes per thread, the first form, made every access of a wave touch 64
     // cache lines: 30 us for 256 KiB).  Wave w of row i = the 256 prefixes of top byte 16 i + w.
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(1024) void hy_scan_kernel(uint32_t* slab, uint32_t*
         }
     }
     if (tid == 0) {
-        info0[PASS_FLAGS] = 0u;
+        info0[PASS_FLAGS] = pregrouped ? PF_SKIP : 0u;  // (pregrouped: pass B reads the alternate buffer, where the grouped input already is)
         info0[I_NCH] = NCH;
         info0[I_NEXT_SHIFT] = 0xffffffffu;
         info0[I_SHIFT] = 24u;
@@ -692,6 +694,20 @@ __global__ __launch_bounds__(THREADS_) void hy_local_sort_pairs_kernel(uint32_t*
             vals[pos] = s_vstage[key[i] >> 16];
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// A sort whose input arrived pre-grouped in the ALTERNATE buffer (hy_scan_kernel's `pregrouped`) and that runs on the LSD passes
+// after all (the plan is void: skewed keys): the LSD plan reads the caller's buffer, so the input is copied there first.  Launched
+// with every pregrouped sort; exits at once when the two-level plan is valid (16-byte words; `words16` of them, the tail by thread 0).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hy_void_copy_kernel(const uint32_t* __restrict__ slab, const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                            size_t words16, const uint32_t* __restrict__ src_tail, uint32_t* __restrict__ dst_tail,
+                                                            uint32_t tail_words) {
+    if (__builtin_amdgcn_readfirstlane((int)slab[SLAB_HY + HY_VALID]) != 0) return;
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < words16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail_words) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
 }  // namespace gs

@@ -150,11 +150,12 @@ class _HostStagedTransport:
             W, me = self.world, self.rank
             for a in range(n_arrays):
                 eb = elem_bytes[a]
-                src = self._d2h(d_send[a], (send_displs[W - 1] + send_counts[W - 1]) * eb, stream)
                 outs = [torch.empty(recv_counts[p] * eb, dtype=torch.uint8) for p in range(W)]
                 reqs = []
                 for p in range(W):
-                    piece = src[send_displs[p] * eb:(send_displs[p] + send_counts[p]) * eb]
+                    # (piece by piece: the library also calls once per top byte — one message per (peer, top byte), gpusort_mgpu.hpp —
+                    #  and then a peer's piece lies anywhere in the send buffer)
+                    piece = self._d2h((d_send[a] or 0) + send_displs[p] * eb, send_counts[p] * eb, stream)
                     if p == me:
                         outs[p].copy_(piece)
                     else:
@@ -183,6 +184,7 @@ class ShardedOneSweep:
         self.always_exchange = always_exchange  # run the split/exchange path even for one rank (single-GPU tests)
         self.last_counts = None
         self.last_split = None    # "top byte" or "12-bit prefix"
+        self.last_bin_major = False  # gs_mgpu_last_layout of the last native sort
         self._ctx = None
         self._transport = None
         if engine is None:
@@ -295,6 +297,9 @@ class ShardedOneSweep:
             d = _plan_dict(plan, self.world)
             self.last_counts = (d["send"], d["recv"])
             self.last_split = "12-bit prefix" if int(plan[3]) else "top byte"  # (profile() would wait for the local sort)
+            bm = C.c_uint32(0)
+            _lib.check(lib.gs_mgpu_last_layout(self._ctx, C.byref(bm)), "gs_mgpu_last_layout")
+            self.last_bin_major = bool(bm.value)  # the bucket was landed top byte by top byte: the local sort skipped its top-byte pass
         return self._recv[:nr], (self._recv_v[:nr] if values is not None else None), nr
 
     # ---- the same steps driven from Python over an injected engine (CPU tests) ------------------------------------

@@ -352,6 +352,11 @@ gs_status gs_mgpu_get_profile(gs_mgpu* ctx, float ms[4], uint64_t* bytes_sent, u
 gs_status gs_mgpu_last_plan(gs_mgpu* ctx, uint32_t* plan, uint32_t words);
 gs_onesweep* gs_mgpu_sorter(gs_mgpu* ctx);               /* the local engine (tuning switches, gs_onesweep_check) */
 gs_status gs_mgpu_set_force_exchange(gs_mgpu* ctx, int on); /* run split + exchange even with one rank (tests) */
+/* How the last gs_onesweep_sort_sharded landed its bucket (host state, no synchronisation): *bin_major = 1 — the bucket exchange went
+ * one message per (peer, top byte) and this rank placed the segments top byte by top byte in the local sort's alternate buffer, so the
+ * local sort started at the two-level plan's second pass (the sender's split WAS its top-byte partition); 0 — source by source in the
+ * output buffer, full local sort (buckets below the two-level plan's size, the 12-bit split, ncclAllToAllv, world 1 without exchange). */
+gs_status gs_mgpu_last_layout(gs_mgpu* ctx, uint32_t* bin_major);
 int gs_last_rccl_error(void);                             /* ncclResult_t of the last failing RCCL call on this thread */
 
 /* The transport the pipeline runs on: RCCL by default; tests run several ranks on ONE GPU over a host-staged one.

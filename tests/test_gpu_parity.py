@@ -429,6 +429,45 @@ def test_sharded_path_single_rank_nccl(gpu, oracle, pairs):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("pairs,andc,kt", [(False, 0, 0), (True, 0, 2), (False, 3, 1), (True, 3, 0)])
+def test_sharded_path_single_rank_bucket_landed_in_the_alternate_buffer(gpu, oracle, monkeypatch, pairs, andc, kt):
+    """Round 6: a bucket that is offered the two-level plan is landed in the local sort's ALTERNATE buffer (here by the RCCL transport's
+    own-bucket copy: one rank, exchange forced) and the local sort starts at the plan's second pass — the split pass was its first.
+    The sorter is offered the plan from 2^20 keys (gs_mgpu_options::sorter: plan 2) so that the path runs at a size the oracle checks
+    in a moment; uniform keys run the plan, entropy preset 4 voids it on the device (hy_void_copy_kernel, four LSD passes); typed keys."""
+    import torch
+    import torch.distributed as dist
+    from gpusorting_amd.sharded import ShardedOneSweep
+    monkeypatch.setenv("GPUSORT_PLAN", "2")
+    monkeypatch.setenv("GPUSORT_POS_MIN_LOG2", "20")
+    monkeypatch.setenv("GPUSORT_MID_PATH", "0")   # (below 2^23 keys the two-launch route would take the bucket)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n = (5 << 20) + 1234
+        keys = oracle.init_random(n, 4321 + andc, andc)
+        vals = np.arange(n, dtype=np.uint32) if pairs else None
+        s = ShardedOneSweep(n, pairs=pairs, value_bytes=4, always_exchange=True, key_type=kt)
+        for rep in range(2):   # (twice on one context: the buffers' roles swap back)
+            bk, bv, nb = s.sort(to_dev(keys), values=None if not pairs else to_dev(vals))
+            s.check()
+            assert nb == n and s.last_bin_major
+            assert s.engine.sorter.last_plan()["two_level"] == (andc == 0)
+            ref = oracle.std_sort(keys, kt, 0, vals)
+            rk, rv = (ref, None) if not pairs else ref
+            np.testing.assert_array_equal(to_host(bk, np.uint32), rk)
+            if pairs:
+                np.testing.assert_array_equal(to_host(bv, np.uint32), rv)
+        s.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("small_path", [True, False])
 @pytest.mark.parametrize("vb,kt,order", [(0, 0, 0), (0, 2, 1), (4, 1, 1), (8, 0, 0), (4, 0, 0)])
 def test_single_tile_path_and_tiled_path_agree(gpu, oracle, small_path, vb, kt, order):

@@ -15,10 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, shard, andc, pairs, q):
+def _worker(rank, world, port, shard, andc, pairs, q, bin_major=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if bin_major is not None:
+        # the local sorter is offered the two-level plan from 2^20 keys (default: 50 M keys / 2^25 + 1 pairs), so that buckets of test size
+        # are landed top byte by top byte and sorted from the plan's second pass on (gs_mgpu_options::sorter through the harness's env)
+        os.environ.update(GPUSORT_PLAN="2", GPUSORT_POS_MIN_LOG2="20", GPUSORT_MID_PATH="0")   # (mid path off: below 2^23 keys the two-launch route would take the bucket)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     import gpusorting_amd as g
@@ -43,6 +47,12 @@ def _worker(rank, world, port, shard, andc, pairs, q):
     torch.cuda.synchronize()
     s.check()   # gs_mgpu_check: no rank carried an error through the exchange, the local sorter is clean
     assert s.last_split == ("12-bit prefix" if andc < 0 else "top byte"), s.last_split
+    if bin_major is not None:
+        assert s.last_bin_major == (bin_major and nb > (1 << 20)), (s.last_bin_major, nb)
+        tl = s.engine.sorter.last_plan()["two_level"] if nb > (1 << 20) else None
+        assert tl is None or tl == (andc == 0), (tl, andc)   # uniform keys: the device runs the plan; preset 4: void -> copy + four LSD passes
+    else:
+        assert not s.last_bin_major
     q.put((rank, k0, v0, bk.cpu().numpy().view(np.uint32).copy(), None if bv is None else bv.cpu().numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,6 +92,35 @@ def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
     for a, b in zip(got[:-1], got[1:]):              # buckets are contiguous ranges of the global order
         if a[3].size and b[3].size:
             assert a[3].max() <= b[3].min()
+
+
+@pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (3 << 20) + 77), (3, 0, True, (3 << 20) + 1), (2, 3, False, (3 << 20) + 5),
+                                                    (2, 3, True, (3 << 20) + 9), (8, 0, False, (3 << 20) + 11), (8, 0, True, (5 << 19) + 3)])
+def test_sharded_sort_bucket_landed_bin_major(gpu, world, andc, pairs, shard):
+    """Round 6: the bucket exchange goes one message per (peer, top byte) and a bucket that is offered the two-level
+    plan is landed top byte by top byte in the local sort's alternate buffer — the sender's split was the top-byte partition — so the
+    local sort starts at pass B.  World 2 / 3 / 8 with the real engine on one GPU; uniform keys (the plan runs) and entropy preset 4 (the
+    device voids the plan: hy_void_copy_kernel + four LSD passes); keys-only and pairs with value = global index (stable across sources)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=480) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    all_keys = np.concatenate([x[1] for x in got])
+    out_keys = np.concatenate([x[3] for x in got])
+    if not pairs:
+        np.testing.assert_array_equal(out_keys, np.sort(all_keys))
+    else:
+        all_vals = np.concatenate([x[2] for x in got])
+        out_vals = np.concatenate([x[4] for x in got])
+        perm = np.argsort(all_keys, kind="stable")   # global stable order: (rank, position)
+        np.testing.assert_array_equal(out_keys, all_keys[perm])
+        np.testing.assert_array_equal(out_vals, all_vals[perm])
 
 
 def _failing_worker(rank, world, port, shard, where, pairs, q):

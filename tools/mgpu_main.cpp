@@ -104,7 +104,7 @@ struct RankResult {  // what a rank reports to rank 0 (plain data: crosses a pip
     float phase[4] = {0, 0, 0, 0};  // split / exchange / local sort / total of the LAST sort (HIP events)
     float kern[GS_PROFILE_SLOTS] = {0};  // per-kernel times of one profiled local sort
     uint64_t sent = 0, recv = 0;
-    uint32_t out_n = 0, first_key = 0, last_key = 0, fine = 0, sorted = 0, status = 0, two_level = 0;
+    uint32_t out_n = 0, first_key = 0, last_key = 0, fine = 0, sorted = 0, status = 0, two_level = 0, bin_major = 0;
 };
 
 #define CHECK_HIP(x)                                                                     \
@@ -160,6 +160,7 @@ int run_rank(const Options& o, int rank, const uint8_t* id, RankResult* out) {
     out->ms_total = wall / o.iters;
     out->status = (unsigned)gs_mgpu_check(ctx, s);
     CHECK_GS(gs_mgpu_get_profile(ctx, out->phase, &out->sent, &out->recv, &out->fine));
+    CHECK_GS(gs_mgpu_last_layout(ctx, &out->bin_major));
     out->out_n = out_n;
     uint32_t err = 1;
     if (out_n) {
@@ -226,12 +227,13 @@ void report(const Options& o, const std::vector<RankResult>& r, const std::vecto
            "\"iters\": %d, \"ms_per_sort\": %.4f, \"scaling\": \"weak\", \"verified\": %s, "
            "\"phase_ms_max_over_ranks\": {\"split\": %.4f, \"exchange\": %.4f, \"local_sort\": %.4f, \"total\": %.4f}, "
            "\"bytes_sent_off_rank\": {\"max\": %llu, \"sum\": %llu}, \"exchange_GBps_per_rank\": %.2f, \"exchange_GBps_per_link\": %.2f, "
-           "\"xgmi_link_peak_GBps\": 153.0, \"links_used_per_rank\": %d, \"frac_of_link_peak\": %.4f, \"split\": \"%s\", "
+           "\"xgmi_link_peak_GBps\": 153.0, \"links_used_per_rank\": %d, \"frac_of_link_peak\": %.4f, \"split\": \"%s\", \"bucket_layout\": \"%s\", "
            "\"local_sort_rank0\": {\"plan\": \"%s\", \"per_kernel_ms\": {\"global_histogram\": %.4f, \"scan\": %.4f, \"pass0\": %.4f, \"pass1\": %.4f, "
            "\"pass2\": %.4f, \"pass3\": %.4f, \"total\": %.4f}, \"roofline\": {\"bound\": \"hbm\", \"kernel\": \"one 8-bit DigitBinningPass\", "
            "\"achieved\": %.1f, \"peak\": 8000.0, \"unit\": \"GB/s\", \"frac\": %.4f}}, \"rank_exit_codes\": [",
            n * W / (ms * 1e-3) / 1e9, W, o.share_gpu ? "threads sharing ONE GPU over an in-process transport (rehearsal, not a scaling number)" : o.threads ? "threads" : "fork", n, o.pairs, o.iters, ms, ok ? "true" : "false", ph[0], ph[1], ph[2],
            ph[3], (unsigned long long)sent_max, (unsigned long long)sent_sum, ex_gbs, ex_gbs / links, W - 1, ex_gbs / links / 153.0, r[0].fine ? "12-bit prefix" : "top byte",
+           r[0].bin_major ? "bin-major in the alternate buffer: the local sort starts at the two-level plan's second pass (phase local_sort)" : "source-major: full local sort",
            r[0].two_level ? "two-level (pass0 = top byte, pass1 = byte 2, pass2 = bucket-local sort)" : "four LSD passes",
            r[0].kern[1], r[0].kern[2], r[0].kern[3], r[0].kern[4], r[0].kern[5], r[0].kern[6], r[0].kern[7], pass_gbs, pass_gbs / 8000.0);
     for (int i = 0; i < W; ++i) printf("%s%d", i ? ", " : "", rc[i]);
