@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_pmc_traffic.json from the summaries tools/rocprof_collect.sh wrote: HBM bytes per working launch of the DigitBinningPass and of the
+"""profiles/r06_pmc_traffic.json from the summaries tools/rocprof_collect.sh wrote: HBM bytes per working launch of the DigitBinningPass and of the
 histogram sweep = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, in KiB per dispatch, with the
 calibration of the same runs (init_random writes 2^30 B; the histogram sweep reads 2^30 B) and the hash of the kernel sources they were measured on
 (bench.py hands the numbers on only for that source state).  usage: tools/make_pmc_json.py IN_DIR COMMIT"""
@@ -31,9 +31,9 @@ def pick(tab, *needles):
 
 def main():
     d, commit = sys.argv[1], sys.argv[2]
-    res = {"round": 5, "commit": commit, "kernel_sources_sha256": bench.kernel_sources_sha256(), "kernel_sources": list(bench.KERNEL_SOURCES),
+    res = {"round": 6, "commit": commit, "kernel_sources_sha256": bench.kernel_sources_sha256(), "kernel_sources": list(bench.KERNEL_SOURCES),
            "collected_by": "tools/rocprof_collect.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --steps 3 "
-                           "--warmup 1 --no-cpu-baseline --no-more [--pairs N]`, 2^28 elements, summaries under profiles/r05_rocprof/",
+                           "--warmup 1 --no-cpu-baseline --no-more [--pairs N]`, 2^28 elements, summaries under profiles/r06_rocprof/",
            "correction": "FETCH_SIZE x 2 on gfx950 (128-byte requests tallied at 64 B); KiB per dispatch; mean over the WORKING dispatches of a kernel "
                          "(a sort also enqueues launches that exit on their flag word)"}
     for cfg, vb in (("keys", 0), ("pairs4", 4), ("pairs8", 8)):
@@ -55,7 +55,7 @@ def main():
         entry["calibration"] = {"init_random_WRITE_SIZE_KiB": gen_w, "expected_KiB": (4 + vb) * n / 1024,
                                 "histogram_FETCH_SIZE_KiB": entry.get("histogram", {}).get("FETCH_SIZE_KiB_per_launch"), "expected_half_KiB": n * 4 / 2048}
         res[cfg] = entry
-    json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_pmc_traffic.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv.get("ratio") for kk, vv in v.items() if isinstance(vv, dict) and "ratio" in vv} for k, v in res.items() if isinstance(v, dict)}))
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 evidence run (GPU box): for keys-only, (u32,u32) and (u32,u64) pairs at 2^28 — rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE
+# Evidence run (round 6 layout) (GPU box): for keys-only, (u32,u32) and (u32,u64) pairs at 2^28 — rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE
 # in runs of their own (counters never together with a trace domain other than --kernel-trace) — of `python bench.py --steps 3 --warmup 1
 # --no-cpu-baseline --no-more [--pairs N]`.  usage: tools/rocprof_collect.sh OUT_DIR   -> OUT_DIR/{keys,pairs4,pairs8}_{stats,fetch,write}.txt
 set -u
-out=${1:-gpurun_out/r05_rocprof}
+out=${1:-gpurun_out/r06_rocprof}
 repo=$(pwd)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
