@@ -152,23 +152,29 @@ def test_withheld_descriptor_times_out_instead_of_hanging(gpu):
 
 def test_mid_route_claimed_but_silent_tile_times_out_instead_of_hanging(gpu):
     """a tile of the mid-size route that was CLAIMED (so nobody can adopt it) but whose counts never appear.  The
-    waiters' bounded spin must expire — GS_ERR_TIMEOUT, seconds, no hang — also while they keep trying to adopt."""
+    waiters' bounded spin must expire — GS_ERR_TIMEOUT, seconds, no hang — also while they keep trying to adopt.
+    (The injected fault needs workgroup 2 of K1 to CLAIM its tile; once in a few hundred runs a neighbour adopts that tile before
+    workgroup 2 is dispatched — then nothing is silent, the sort simply completes, and must be exact.  Seen once in round 6's full
+    runs: each case is tried up to six times, every completed sort is validated, and a timeout must be seen.)"""
     out = _run("libgpusort_fault_nofallback.so", """
         import sys, time, torch
         sys.path.insert(0, %r)
         import gpusorting_amd as g
         for n, pairs in ((200000, False), ((1 << 20) + 3, True)):
-            k = torch.empty(n, dtype=torch.int32, device="cuda")
-            g.init_random(k, 10, 0)
-            v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
-            s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
-            t0 = time.time()
-            s.sort(k, v)
-            try:
-                s.check()
-                print("RESULT no-timeout")
-            except g.GpuSortError as e:
-                print("RESULT status", e.status, "seconds", round(time.time() - t0, 3))
+            for attempt in range(6):
+                k = torch.empty(n, dtype=torch.int32, device="cuda")
+                g.init_random(k, 10 + attempt, 0)
+                v = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+                s = g.OneSweep(n, mode=g.MODE_PAIRS if pairs else g.MODE_KEYS_ONLY, value_bytes=4 if pairs else 0)
+                t0 = time.time()
+                s.sort(k, v)
+                try:
+                    s.check()
+                    print("COMPLETED sorted", g.validate(k) == 0)
+                except g.GpuSortError as e:
+                    print("RESULT status", e.status, "seconds", round(time.time() - t0, 3))
+                    break
     """)
-    assert out.count("RESULT status 4") == 2, out   # GS_ERR_TIMEOUT
+    assert out.count("RESULT status 4") == 2, out   # GS_ERR_TIMEOUT, once per case
     assert all(float(x.split()[0]) < 20.0 for x in out.split("seconds")[1:])
+    assert "COMPLETED sorted False" not in out, out
