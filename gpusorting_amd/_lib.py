@@ -37,7 +37,7 @@ class OneSweepOptions(C.Structure):
 
 class MgpuOptions(C.Structure):
     """gs_mgpu_options (include/gpusort.h)."""
-    _fields_ = [("struct_size", C.c_uint32), ("force_exchange", C.c_int32), ("overlap", C.c_int32), ("alltoallv", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("force_exchange", C.c_int32), ("overlap", C.c_int32), ("alltoallv", C.c_int32), ("by_bin", C.c_int32),
                 ("sorter", OneSweepOptions)]
 
 
@@ -84,7 +84,7 @@ def mgpu_options_from_env(**overrides) -> "MgpuOptions":
     load().gs_mgpu_options_default(C.byref(o))
     o.sorter = onesweep_options_from_env()  # the context's local sorter follows the same GPUSORT_* switches
     for name, field in (("GPUSORT_MGPU_FORCE_EXCHANGE", "force_exchange"), ("GPUSORT_MGPU_OVERLAP", "overlap"),
-                        ("GPUSORT_MGPU_ALLTOALLV", "alltoallv")):
+                        ("GPUSORT_MGPU_ALLTOALLV", "alltoallv"), ("GPUSORT_MGPU_BY_BIN", "by_bin")):
         if name in os.environ:
             try:
                 setattr(o, field, int(os.environ[name], 0))

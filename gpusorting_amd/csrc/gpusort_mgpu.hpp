@@ -177,6 +177,7 @@ struct gs_mgpu {
     uint32_t* h_status;        // pinned mirror
     int overlap;               // values on the second stream (gs_mgpu_options::overlap, default 1)
     int alltoallv;             // the RCCL transport exchanges through ncclAllToAllv (gs_mgpu_options::alltoallv)
+    int by_bin;                // the grouped exchange goes one message per (peer, top byte) (gs_mgpu_options::by_bin, default 1)
     int failed;                // a call on this context has failed: destroy aborts the communicators
     bool call_complete = true; // the last gs_onesweep_sort_sharded ran through its closing status gather and returned GS_OK on this
                                // rank: only then are d_status[1..world] THIS call's words (gs_mgpu_check reads nothing otherwise)
@@ -237,6 +238,7 @@ gs_status mgpu_new(gs_mgpu** out, uint32_t rank, uint32_t world, uint32_t shard_
     c->force_exchange = o.force_exchange ? 1 : 0;
     c->overlap = o.overlap ? 1 : 0;
     c->alltoallv = o.alltoallv ? 1 : 0;
+    c->by_bin = o.by_bin ? 1 : 0;
     gs_status st = gs_onesweep_create_ex(&c->sorter, capacity, mode, value_bytes, o.sorter.struct_size ? &o.sorter : nullptr);
     if (st == GS_OK) st = mgpu_alloc(c);
     if (st != GS_OK) { gs_mgpu_destroy(c); return st; }
@@ -299,6 +301,7 @@ void gs_mgpu_options_default(gs_mgpu_options* o) {
     memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t)sizeof(*o);
     o->overlap = 1;
+    o->by_bin = 1;
 }
 
 gs_status gs_mgpu_create(gs_mgpu** out, const uint8_t id[GS_MGPU_UNIQUE_ID_BYTES], uint32_t rank, uint32_t world,
@@ -477,7 +480,7 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         // Layout of the received bucket (this rank's own decision): bin-major in the local sort's ALTERNATE buffer if that sort will be
         // offered the two-level plan — its top-byte pass is then behind us — source-major in the caller's buffer otherwise.
         // Messages per (peer, top byte): whenever the exchange can carry them (not the 12-bit split, not ncclAllToAllv).
-        const bool by_bin = !fine && !(c->owns_comm && c->alltoallv);
+        const bool by_bin = c->by_bin && !fine && !(c->owns_comm && c->alltoallv);
         const bool pre = by_bin && n_recv != 0 && sort_route(h, n_recv, kt, vb).hy;
         c->last_pregrouped = pre ? 1u : 0u;
         uint32_t* const split_keys = pre ? static_cast<uint32_t*>(d_out_keys) : c->part_keys;  // where the shard is grouped = the send buffer

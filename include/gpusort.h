@@ -307,6 +307,9 @@ typedef struct gs_mgpu_options {
     int32_t force_exchange; /* 0 (default); 1: a single rank runs partition + exchange too (tests: world == 1 normally just sorts) */
     int32_t overlap;        /* 1 (default): pairs send their values on a second stream / communicator behind the keys; 0: one group */
     int32_t alltoallv;      /* 0 (default): grouped ncclSend / ncclRecv; 1: ncclAllToAllv (also switchable later: gs_mgpu_set_alltoallv) */
+    int32_t by_bin;         /* 1 (default): the grouped exchange goes one message per (peer, top byte), so that a bucket offered the two-level plan
+                               is landed bin-major and its local sort starts at the plan's second pass (gs_mgpu_last_layout); 0: one message
+                               per peer, source-major landing, full local sort (round 5's exchange; what ncclAllToAllv and the 12-bit split always use) */
     gs_onesweep_options sorter;  /* options of the context's local sorter (gs_mgpu_sorter); struct_size 0 = defaults */
 } gs_mgpu_options;
 void gs_mgpu_options_default(gs_mgpu_options* o);

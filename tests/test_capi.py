@@ -66,7 +66,7 @@ def test_options_structs_match_the_header_defaults(monkeypatch):
             o.plan, o.first_pass_big, o.hist_blocks, o.debug_flags) == (-1, 1, 1, 1, 1, 25, 1, 0, 1, 0, 0)
     m = _lib.MgpuOptions()
     lib.gs_mgpu_options_default(C.byref(m))
-    assert m.struct_size == C.sizeof(_lib.MgpuOptions) and (m.force_exchange, m.overlap, m.alltoallv) == (0, 1, 0)
+    assert m.struct_size == C.sizeof(_lib.MgpuOptions) and (m.force_exchange, m.overlap, m.alltoallv, m.by_bin) == (0, 1, 0, 1)
     # the harness' translation of the environment
     monkeypatch.setenv("GPUSORT_MID_PATH", "0")
     monkeypatch.setenv("GPUSORT_POS", "2")

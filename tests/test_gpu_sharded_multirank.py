@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, shard, andc, pairs, q, bin_major=None):
+def _worker(rank, world, port, shard, andc, pairs, q, bin_major=None, empty_rank=-1):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -40,6 +40,8 @@ def _worker(rank, world, port, shard, andc, pairs, q, bin_major=None):
     else:
         g.init_random(keys, 10 + 1000 * rank, andc)
     vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
+    if rank == empty_rank:   # this rank brings nothing: it still takes part in every collective and receives its bucket
+        keys, vals = keys[:0], (None if vals is None else vals[:0])
     k0 = keys.cpu().numpy().view(np.uint32).copy()
     v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
     s = ShardedOneSweep(shard, slack=slack, pairs=pairs, value_bytes=4)   # the C++ pipeline (gs_onesweep_sort_sharded) over a host-staged transport
@@ -94,9 +96,10 @@ def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
             assert a[3].max() <= b[3].min()
 
 
-@pytest.mark.parametrize("world,andc,pairs,shard", [(2, 0, False, (3 << 20) + 77), (3, 0, True, (3 << 20) + 1), (2, 3, False, (3 << 20) + 5),
-                                                    (2, 3, True, (3 << 20) + 9), (8, 0, False, (3 << 20) + 11), (8, 0, True, (5 << 19) + 3)])
-def test_sharded_sort_bucket_landed_bin_major(gpu, world, andc, pairs, shard):
+@pytest.mark.parametrize("world,andc,pairs,shard,empty_rank", [(2, 0, False, (3 << 20) + 77, -1), (3, 0, True, (3 << 20) + 1, -1), (2, 3, False, (3 << 20) + 5, -1),
+                                                               (2, 3, True, (3 << 20) + 9, -1), (8, 0, False, (3 << 20) + 11, -1), (8, 0, True, (5 << 19) + 3, -1),
+                                                               (3, 0, True, (5 << 20) + 7, 1), (3, 0, False, (5 << 20) + 7, 0)])
+def test_sharded_sort_bucket_landed_bin_major(gpu, world, andc, pairs, shard, empty_rank):
     """Round 6: the bucket exchange goes one message per (peer, top byte) and a bucket that is offered the two-level
     plan is landed top byte by top byte in the local sort's alternate buffer — the sender's split was the top-byte partition — so the
     local sort starts at pass B.  World 2 / 3 / 8 with the real engine on one GPU; uniform keys (the plan runs) and entropy preset 4 (the
@@ -104,7 +107,7 @@ def test_sharded_sort_bucket_landed_bin_major(gpu, world, andc, pairs, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard, andc, pairs, q, True, empty_rank)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=480) for _ in range(world)), key=lambda t: t[0])
@@ -205,6 +208,8 @@ def _rccl_worker(rank, world, port, shard, pairs, alltoallv, q):
     keys = torch.empty(shard, dtype=torch.int32, device="cuda")
     g.init_random(keys, 10 + 1000 * rank, 0)
     vals = (torch.arange(shard, dtype=torch.int32, device="cuda") + rank * shard) if pairs else None
+    if rank == empty_rank:   # this rank brings nothing: it still takes part in every collective and receives its bucket
+        keys, vals = keys[:0], (None if vals is None else vals[:0])
     k0 = keys.cpu().numpy().view(np.uint32).copy()
     v0 = None if vals is None else vals.cpu().numpy().view(np.uint32).copy()
     s = ShardedOneSweep(shard, pairs=pairs, value_bytes=4)   # gs_mgpu_create_ex: ncclCommInitRank (+ ncclCommSplit for the values)
