@@ -96,9 +96,9 @@ def test_sharded_sort_real_engine_over_gloo(gpu, world, andc, pairs, shard):
             assert a[3].max() <= b[3].min()
 
 
-@pytest.mark.parametrize("world,andc,pairs,shard,empty_rank", [(2, 0, False, (3 << 20) + 77, -1), (3, 0, True, (3 << 20) + 1, -1), (2, 3, False, (3 << 20) + 5, -1),
-                                                               (2, 3, True, (3 << 20) + 9, -1), (8, 0, False, (3 << 20) + 11, -1), (8, 0, True, (5 << 19) + 3, -1),
-                                                               (3, 0, True, (5 << 20) + 7, 1), (3, 0, False, (5 << 20) + 7, 0)])
+@pytest.mark.parametrize("world,andc,pairs,shard,empty_rank", [(2, 0, False, (3 << 19) + 77, -1), (3, 0, True, (3 << 19) + 1, -1), (2, 3, False, (3 << 20) + 5, -1),
+                                                               (2, 3, True, (3 << 20) + 9, -1), (8, 0, False, (9 << 17) + 11, -1), (8, 0, True, (9 << 17) + 3, -1),
+                                                               (3, 0, True, (7 << 18) + 7, 1), (3, 0, False, (7 << 18) + 7, 0)])
 def test_sharded_sort_bucket_landed_bin_major(gpu, world, andc, pairs, shard, empty_rank):
     """Round 6: the bucket exchange goes one message per (peer, top byte) and a bucket that is offered the two-level
     plan is landed top byte by top byte in the local sort's alternate buffer — the sender's split was the top-byte partition — so the
