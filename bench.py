@@ -543,7 +543,8 @@ def headline_line(out: dict) -> str:
     if mg:
         line["multi_gpu"] = {"phase_ms_max_over_ranks": {k: _r(v) for k, v in mg["phase_ms_max_over_ranks"].items()},
                              "exchange_GBps_per_link": _r(mg["exchange_GBps_per_link"], 1), "frac_of_link_peak": _r(mg["frac_of_link_peak"]),
-                             "pipeline": mg["pipeline"].split(":")[0][:80]}
+                             "pipeline": mg["pipeline"].split(":")[0][:80], "bucket_layout": str(mg.get("bucket_layout", "")).split(" in ")[0].split(":")[0][:24],
+                             "exchange_call_ab": mg.get("exchange_call_ab")}
     more = out.get("more")
     if more:
         dg = {}
