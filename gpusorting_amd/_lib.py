@@ -153,6 +153,7 @@ _PROTOS = [
     ("gs_mgpu_sorter", _vp, [_vp]),
     ("gs_mgpu_set_force_exchange", _int, [_vp, _int]),
     ("gs_mgpu_last_layout", _int, [_vp, _u32p]),
+    ("gs_msd_exchange_round", _int, [_u32p, _u32, _u32, _u32p, _int, _u32, _u32p, _u32p, _u32p, _u32p, _u32p]),
     ("gs_last_rccl_error", _int, []),
     ("gs_mgpu_create_with_transport", _int, [C.POINTER(_vp), C.POINTER(MgpuTransport), _u32, _u32, _u32, _u32, _int, _u32]),
     ("gs_msd_plan", _int, [_u32p, _u32, _u32, _u32, _u32, _u32p]),

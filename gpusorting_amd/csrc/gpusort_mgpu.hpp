@@ -518,42 +518,20 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         }
         // Rounds: round j carries, for every peer p, top byte first[p] + j of p's range (ONE round with whole buckets if the exchange
         // goes peer by peer, or with one rank: a single source is bin-major as it is).  Both sides derive every count from the same
-        // gathered table; messages between two ranks are matched in the order they are issued, bin by bin.
+        // gathered table (gs_msd_exchange_round: a host function, checked on its own in tests/test_capi.py); messages between two
+        // ranks are matched in the order they are issued, bin by bin.
         const uint32_t* first = recv + W;              // first_bin[world + 1]
-        const uint32_t* T = c->h_table;                // [source][top byte]
         const bool rounds_by_bin = by_bin && W > 1;
         uint32_t R = 1;
-        std::vector<uint32_t> L, D;                    // start of bin b in my grouped shard; landing place of (source q, my bin j)
-        if (rounds_by_bin) {
-            R = 0;
-            for (uint32_t p = 0; p < W; ++p) R = first[p + 1] - first[p] > R ? first[p + 1] - first[p] : R;
-            L.assign(gs::RADIX + 1, 0);
-            for (uint32_t x = 0; x < gs::RADIX; ++x) L[x + 1] = L[x] + T[(size_t)c->rank * gs::RADIX + x];
-            const uint32_t f0 = first[c->rank], nb = first[c->rank + 1] - f0;
-            D.assign((size_t)W * (nb ? nb : 1), 0);
-            uint32_t run = 0;
-            if (pre) { for (uint32_t j = 0; j < nb; ++j) for (uint32_t q = 0; q < W; ++q) { D[(size_t)q * nb + j] = run; run += T[(size_t)q * gs::RADIX + f0 + j]; } }
-            else     { for (uint32_t q = 0; q < W; ++q) for (uint32_t j = 0; j < nb; ++j) { D[(size_t)q * nb + j] = run; run += T[(size_t)q * gs::RADIX + f0 + j]; } }
-        }
         std::vector<uint32_t> sc(W), sdp(W), rc(W), rdp(W);
-        auto round_counts = [&](uint32_t j) {
-            const uint32_t f0 = first[c->rank], nb = first[c->rank + 1] - f0;
-            for (uint32_t p = 0; p < W; ++p) {
-                const uint32_t bp = first[p] + j;      // the byte of p's range this round carries
-                const bool sends = bp < first[p + 1];
-                sc[p] = sends ? T[(size_t)c->rank * gs::RADIX + bp] : 0u;
-                sdp[p] = sends ? L[bp] : 0u;
-                rc[p] = j < nb ? T[(size_t)p * gs::RADIX + f0 + j] : 0u;
-                rdp[p] = j < nb ? D[(size_t)p * nb + j] : 0u;
-            }
-        };
+        if (rounds_by_bin && gs_msd_exchange_round(c->h_table, W, c->rank, first, pre ? 1 : 0, 0, sc.data(), sdp.data(), rc.data(), rdp.data(), &R) != GS_OK) note(GS_ERR_ARG);
         // all rounds of one array set in ONE ncclGroup (nested groups merge): one launch, every link busy from the start
         auto exchange_all = [&](const gs_mgpu_transport& t, uint32_t n_arrays, const void* const* src_, void* const* dst_, const uint32_t* eb_, hipStream_t st_) -> int {
             if (!rounds_by_bin) return t.exchange(t.user, n_arrays, src_, dst_, eb_, send, sd.data(), recv, rd.data(), st_);
             const bool grouped = c->owns_comm && rccl() != nullptr;
             int e = grouped ? rccl()->GroupStart() : 0;
             for (uint32_t j = 0; j < R && !e; ++j) {
-                round_counts(j);
+                if (gs_msd_exchange_round(c->h_table, W, c->rank, first, pre ? 1 : 0, j, sc.data(), sdp.data(), rc.data(), rdp.data(), nullptr) != GS_OK) { e = -1; break; }
                 e = t.exchange(t.user, n_arrays, src_, dst_, eb_, sc.data(), sdp.data(), rc.data(), rdp.data(), st_);
             }
             const int e2 = grouped ? rccl()->GroupEnd() : 0;
@@ -692,6 +670,50 @@ gs_status gs_msd_plan(const uint32_t* table, uint32_t nbins, uint32_t world, uin
     plan[gs::PLAN_OVERFLOW] = mx > capacity ? 1u : 0u;
     plan[gs::PLAN_MAXBUCKET] = (uint32_t)(mx > 0xffffffffull ? 0xffffffffull : mx);
     plan[3] = 0;
+    return GS_OK;
+}
+
+gs_status gs_msd_exchange_round(const uint32_t* table, uint32_t world, uint32_t rank, const uint32_t* first_bin, int bin_major, uint32_t round,
+                                uint32_t* send_counts, uint32_t* send_displs, uint32_t* recv_counts, uint32_t* recv_displs, uint32_t* rounds) {
+    if (!table || !first_bin || world == 0 || world > gs::MSD_MAX_WORLD || rank >= world || !send_counts || !send_displs || !recv_counts || !recv_displs)
+        return GS_ERR_ARG;
+    constexpr uint32_t NB = gs::RADIX;
+    if (first_bin[0] != 0 || first_bin[world] != NB) return GS_ERR_ARG;
+    uint32_t R = 0;
+    for (uint32_t p = 0; p < world; ++p) {
+        if (first_bin[p + 1] < first_bin[p]) return GS_ERR_ARG;
+        R = first_bin[p + 1] - first_bin[p] > R ? first_bin[p + 1] - first_bin[p] : R;
+    }
+    if (rounds) *rounds = R;
+    const uint32_t f0 = first_bin[rank], nb = first_bin[rank + 1] - f0;
+    const uint32_t* mine = table + (size_t)rank * NB;
+    // where this rank's bytes start in its own grouped shard (the split pass wrote them in byte order), up to the bytes this round sends
+    for (uint32_t p = 0; p < world; ++p) {
+        const uint32_t bp = first_bin[p] + round;      // the byte of p's range this round carries
+        const bool sends = bp < first_bin[p + 1];
+        uint32_t off = 0;
+        if (sends) for (uint32_t x = 0; x < bp; ++x) off += mine[x];
+        send_counts[p] = sends ? mine[bp] : 0u;
+        send_displs[p] = off;
+    }
+    // where (source q, my byte f0 + round) lands: bin-major = byte by byte, sources in rank order inside a byte (the stable top-byte
+    // partition of the concatenated sources); source-major = source by source, a source's bytes in order (round 5's layout)
+    for (uint32_t q = 0; q < world; ++q) {
+        uint32_t off = 0, cnt = 0;
+        if (round < nb) {
+            const uint32_t b = f0 + round;
+            cnt = table[(size_t)q * NB + b];
+            if (bin_major) {
+                for (uint32_t j = 0; j < round; ++j) for (uint32_t s = 0; s < world; ++s) off += table[(size_t)s * NB + f0 + j];
+                for (uint32_t s = 0; s < q; ++s) off += table[(size_t)s * NB + b];
+            } else {
+                for (uint32_t s = 0; s < q; ++s) for (uint32_t j = 0; j < nb; ++j) off += table[(size_t)s * NB + f0 + j];
+                for (uint32_t j = 0; j < round; ++j) off += table[(size_t)q * NB + f0 + j];
+            }
+        }
+        recv_counts[q] = cnt;
+        recv_displs[q] = off;
+    }
     return GS_OK;
 }
 

@@ -381,6 +381,14 @@ gs_status gs_mgpu_create_with_transport(gs_mgpu** out, const gs_mgpu_transport* 
 /* The plan as a host function (same rule as the device kernel; CPU tests, other transports): table[src * nbins + b] =
  * keys of rank src in MSD bin b. */
 gs_status gs_msd_plan(const uint32_t* table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity, uint32_t* plan);
+/* One round of the per-(peer, top byte) bucket exchange as gs_onesweep_sort_sharded runs it (host function, no GPU: CPU tests, other
+ * transports).  table[src * 256 + b] = keys of rank src under top byte b (the gathered table of the coarse split); first_bin[world + 1] =
+ * the plan's splitters.  Round `round` carries, for every peer p, byte first_bin[p] + round of p's range: send_counts / send_displs[p]
+ * (elements, in this rank's shard grouped by top byte) and recv_counts / recv_displs[q] for this rank's own byte first_bin[rank] + round
+ * from every source q — landed bin-major (bin_major != 0: byte by byte, sources in rank order inside a byte = the stable top-byte
+ * partition of the concatenated sources) or source-major.  *rounds (may be NULL) = rounds of a call = the widest rank's byte count. */
+gs_status gs_msd_exchange_round(const uint32_t* table, uint32_t world, uint32_t rank, const uint32_t* first_bin, int bin_major, uint32_t round,
+                                uint32_t* send_counts, uint32_t* send_displs, uint32_t* recv_counts, uint32_t* recv_displs, uint32_t* rounds);
 /* Test hook: the device plan kernel on a host table (nbins 256 or 4096); synchronous. */
 gs_status gs_debug_msd_plan_device(const uint32_t* h_table, uint32_t nbins, uint32_t world, uint32_t rank, uint32_t capacity,
                                    uint32_t* h_plan, void* stream);

@@ -237,3 +237,67 @@ def test_bench_headline_line_is_small_and_complete():
     # the counters file the line borrows `traffic` from exists and names the sources it was measured on
     path = bench.pmc_traffic_file()
     assert path and "kernel_sources_sha256" in json.load(open(path))
+
+
+@pytest.mark.parametrize("world,bin_major", [(2, 1), (3, 1), (8, 1), (8, 0), (5, 1)])
+def test_bucket_exchange_rounds_land_the_stable_top_byte_partition(world, bin_major):
+    """Round 6, multi-GPU (no GPU needed): the per-(peer, top byte) exchange rounds of gs_onesweep_sort_sharded — the host function the
+    pipeline itself calls (gs_msd_exchange_round) — replayed over numpy shards.  Every rank's shard is grouped by top byte (what the
+    split pass leaves); the rounds' messages are delivered; a bin-major landing must hold EXACTLY the stable top-byte partition of the
+    concatenated sources restricted to the rank's byte range (so that the local sort can start at its second pass), a source-major
+    landing the sources one after another; uneven splitters, empty bytes and an empty shard included."""
+    from gpusorting_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(600 + world)
+    # shards: (key, id) with id = global index; rank 1 of a 3-rank world brings nothing
+    shards = []
+    gid = 0
+    for r in range(world):
+        n = 0 if (world == 3 and r == 1) else int(rng.integers(2000, 5000))
+        top = (rng.integers(0, 256, size=n) if r % 2 else np.minimum(rng.integers(0, 256, size=n), rng.integers(0, 300, size=n)).clip(0, 255)).astype(np.uint32)
+        top[(top > 40) & (top < 60)] = 41                     # some empty bytes
+        keys = (top << 24) | rng.integers(0, 1 << 24, size=n).astype(np.uint32)
+        ids = np.arange(gid, gid + n, dtype=np.uint32)
+        gid += n
+        order = np.argsort(keys >> 24, kind="stable")         # the split pass: stable by top byte
+        shards.append((keys[order], ids[order]))
+    table = np.zeros((world, 256), dtype=np.uint32)
+    for r, (k, _) in enumerate(shards):
+        table[r] = np.bincount(k >> 24, minlength=256)
+    plan = np.zeros(4 + 3 * world + 1, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    assert lib.gs_msd_plan(table.ctypes.data_as(u32p), 256, world, 0, 1 << 30, plan.ctypes.data_as(u32p)) == _lib.GS_OK
+    first = np.ascontiguousarray(plan[4 + 2 * world:4 + 3 * world + 1])
+    assert first[0] == 0 and first[-1] == 256
+    n_recv = [int(table[:, first[r]:first[r + 1]].sum()) for r in range(world)]
+    land_k = [np.full(n, 0xFFFFFFFF, dtype=np.uint32) for n in n_recv]
+    land_i = [np.full(n, 0xFFFFFFFF, dtype=np.uint32) for n in n_recv]
+    rounds = C.c_uint32(0)
+    sc, sd, rc, rd = (np.zeros(world, dtype=np.uint32) for _ in range(4))
+    per_rank = {}
+    for r in range(world):
+        assert lib.gs_msd_exchange_round(table.ctypes.data_as(u32p), world, r, first.ctypes.data_as(u32p), bin_major, 0, sc.ctypes.data_as(u32p),
+                                         sd.ctypes.data_as(u32p), rc.ctypes.data_as(u32p), rd.ctypes.data_as(u32p), C.byref(rounds)) == _lib.GS_OK
+        assert rounds.value == int((first[1:] - first[:-1]).max())
+    for j in range(rounds.value):
+        for r in range(world):
+            assert lib.gs_msd_exchange_round(table.ctypes.data_as(u32p), world, r, first.ctypes.data_as(u32p), bin_major, j, sc.ctypes.data_as(u32p),
+                                             sd.ctypes.data_as(u32p), rc.ctypes.data_as(u32p), rd.ctypes.data_as(u32p), None) == _lib.GS_OK
+            per_rank[r] = (sc.copy(), sd.copy(), rc.copy(), rd.copy())
+        for src in range(world):                              # deliver: what src sends to dst is what dst expects from src
+            for dst in range(world):
+                cnt, off = int(per_rank[src][0][dst]), int(per_rank[src][1][dst])
+                assert cnt == int(per_rank[dst][2][src])
+                at = int(per_rank[dst][3][src])
+                land_k[dst][at:at + cnt] = shards[src][0][off:off + cnt]
+                land_i[dst][at:at + cnt] = shards[src][1][off:off + cnt]
+    all_k = np.concatenate([s[0] for s in shards])
+    all_i = np.concatenate([s[1] for s in shards])
+    for r in range(world):
+        mine = ((all_k >> 24) >= first[r]) & ((all_k >> 24) < first[r + 1])
+        k, i = all_k[mine], all_i[mine]                       # sources in rank order, each grouped by top byte
+        if bin_major:
+            o = np.argsort(k >> 24, kind="stable")            # the stable top-byte partition of the concatenated sources
+            k, i = k[o], i[o]
+        np.testing.assert_array_equal(land_k[r], k)
+        np.testing.assert_array_equal(land_i[r], i)
