@@ -481,7 +481,14 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
         // offered the two-level plan — its top-byte pass is then behind us — source-major in the caller's buffer otherwise.
         // Messages per (peer, top byte): whenever the exchange can carry them (not the 12-bit split, not ncclAllToAllv).
         const bool by_bin = c->by_bin && !fine && !(c->owns_comm && c->alltoallv);
-        const bool pre = by_bin && n_recv != 0 && sort_route(h, n_recv, kt, vb).hy;
+        // (the bin-major path groups the shard INTO the output buffers: a caller whose input overlaps its output keeps the other layout)
+        auto overlaps = [](const void* a, size_t na, const void* b, size_t nb) {
+            const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+            return a && b && x < y + nb && y < x + na;
+        };
+        const bool aliased = overlaps(d_keys, (size_t)n * 4, d_out_keys, (size_t)c->capacity * 4) ||
+                             (vb && overlaps(d_vals, (size_t)n * vb, d_out_vals, (size_t)c->capacity * vb));
+        const bool pre = by_bin && !aliased && n_recv != 0 && sort_route(h, n_recv, kt, vb).hy;
         c->last_pregrouped = pre ? 1u : 0u;
         uint32_t* const split_keys = pre ? static_cast<uint32_t*>(d_out_keys) : c->part_keys;  // where the shard is grouped = the send buffer
         void* const split_vals = pre ? d_out_vals : c->part_vals;
