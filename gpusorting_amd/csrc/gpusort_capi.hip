@@ -648,56 +648,46 @@ gs_status sort_impl(gs_onesweep* h, void* d_keys, void* d_vals, void* d_alt_keys
                                    vw / 4, static_cast<const uint32_t*>(d_alt_vals) + (vw & ~(size_t)3), static_cast<uint32_t*>(d_vals) + (vw & ~(size_t)3), (uint32_t)(vw & 3));
             }
         }
+        // one launch of pass p: form `f` on `grid` workgroups, reading k[a] / v[a] and writing the other pair, with pass p's scan state
+        auto launch = [&](BinLauncher f, uint32_t grid, uint32_t p, uint32_t a, uint32_t shift, uint32_t mode) {
+            f(s, grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
+              h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE, h->slab + SLAB_INFO + p * gs::INFO_STRIDE,
+              h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, shift, mode);
+        };
+        const bool skip_local = (h->debug_flags & 0x40000000u) != 0u;  // (tuning builds, tools/hy_bringup.py: pass B's output stays as it is)
         for (uint32_t p = 0; p < NP; ++p) {
             const uint32_t a = dyn ? 0u : (p & 1u);
             const uint32_t mode = (dyn ? (desc_bit | gs::BM_PLANNED) : ((desc_bit && p == NP - 1) ? gs::BM_REVERSE : 0u)) | (p == 0 ? gs::BM_ZERO_HIST : 0u);
-            // 8-byte values on the big tile: two forms of the pass are launched, the skew flag picks one (see BinCfg::VROUNDS)
-            const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
-            if (pos && vb == 0) {  // one launch serves both plans (persistent workgroups, two per CU)
-                // two-level plan: the first two launches are pass A / pass B or LSD passes 0 / 1 — digit and chain count come from the
-                // info block (BM_INFO_SHIFT, BM_INFO_CHAINS); the bucket-local sort follows them; LSD passes 2 and 3 exit on PF_SKIP if it ran
-                g_dual[p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-                                   h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-                                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
-                                   mode | ((hy && p < 2) ? gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS : 0u) | ((hy && p == 1) ? gs::BM_ZERO_DESC23 : 0u));
+            if (pos && vb == 0) {
+                // (1) keys-only sorts that may run on position chains: ONE launch per pass serves every plan (persistent workgroups, two per
+                // CU).  Offered the two-level plan, the first two launches are pass A / pass B or LSD passes 0 / 1 — digit and chain count come
+                // from the info block — the bucket-local sort follows them, and LSD passes 2 and 3 exit on PF_SKIP if it ran.
+                launch(g_dual[p == 3][kt], pos_grid(), p, a, p * 8,
+                       mode | ((hy && p < 2) ? gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS : 0u) | ((hy && p == 1) ? gs::BM_ZERO_DESC23 : 0u));
                 if (hy && p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));  // slot 4 = pass B; slot 5: the local sort (+ LSD pass 2's launch); slot 6: LSD pass 3's
-                    HyLocalLauncher local = g_hy_local[hy_class(n)][kt];
-                    // (debug bit 30, tools/hy_bringup.py: pass B's output stays as it is)
-                    if (!(h->debug_flags & 0x40000000u)) local(s, gs::HY_BINS, k[0], h->hy_tab, h->slab, n, desc_bit);
+                    if (!skip_local) g_hy_local[hy_class(n)][kt](s, gs::HY_BINS, k[0], h->hy_tab, h->slab, n, desc_bit);
                 }
             } else if (hy) {
-                // pairs that may run on the two-level plan: launches 0 and 1 = its two DigitBinningPasses (the plain form as persistent
+                // (2) pairs that are offered the two-level plan: launches 0 and 1 = its two DigitBinningPasses (the plain form as persistent
                 // workgroups: digit and chain count from the info block) or, on position chains, LSD passes 0 and 1 (the position-chain
                 // form, which also serves LSD passes 2 and 3); the bucket-local sort sits between them.  The non-persistent plain forms
                 // are not launched at all: whichever plan the device picks, one of these two forms is the one that works.
-                uint32_t* d_p = h->slab + SLAB_DESC + (size_t)p * plan.desc_stride;
-                uint32_t* c_p = h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE;
-                const uint32_t* i_p = h->slab + SLAB_INFO + p * gs::INFO_STRIDE;
-                if (p < 2)
-                    g_persist[vb == 8][kt](s, pos_grid() / 2u, k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                           p * 8, mode | gs::BM_FORMS | gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS);
-                g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], d_p, c_p, i_p, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                            p * 8, (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS | (p == 1 ? gs::BM_ZERO_DESC23 : 0u));
+                if (p < 2) launch(g_persist[vb == 8][kt], pos_grid() / 2u, p, a, p * 8, mode | gs::BM_FORMS | gs::BM_INFO_SHIFT | gs::BM_INFO_CHAINS);
+                launch(g_posv[vb == 8][p == 3][kt], pos_grid(), p, a, p * 8, (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS | (p == 1 ? gs::BM_ZERO_DESC23 : 0u));
                 if (p == 1) {
                     if (h->profiling) GS_HIP(hipEventRecord(h->ev[5], s));
-                    if (!(h->debug_flags & 0x40000000u)) g_hy_local_pairs[vb == 8][hy_class(n)][kt](s, k[0], v[0], h->hy_tab, h->slab, n, desc_bit);
+                    if (!skip_local) g_hy_local_pairs[vb == 8][hy_class(n)][kt](s, k[0], v[0], h->hy_tab, h->slab, n, desc_bit);
                 }
-            } else
-                (p == 0 ? fn0 : fn)(s, p == 0 ? plan.grid0 : plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-                   h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, word * 32 + p * 8,
-                   mode | (two_forms ? gs::BM_IF_EVEN : 0u) | ((pos && vb != 0) ? gs::BM_FORMS : 0u) | exp_mode);
-            if (two_forms && !hy)
-                g_vr2[h->rank_mode][kt](s, plan.grid, k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-                                        h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-                                        h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n,
-                                        word * 32 + p * 8, mode | gs::BM_IF_SKEW | ((pos && vb == 8) ? gs::BM_FORMS : 0u));
-            if (pos && vb != 0 && !hy)  // pairs: the position-chain form is a launch of its own (the plan's flags pick one of the two or three)
-                g_posv[vb == 8][p == 3][kt](s, pos_grid(), k[a], k[a ^ 1u], v[a], v[a ^ 1u], h->slab + SLAB_DESC + (size_t)p * plan.desc_stride,
-                                   h->slab + SLAB_COUNTERS + p * gs::COUNTERS_PER_PASS * gs::COUNTER_STRIDE,
-                                   h->slab + SLAB_INFO + p * gs::INFO_STRIDE, h->slab + gs::SLAB_HSUB, h->slab + SLAB_STATUS, n, p * 8,
-                                   (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS);
+            } else {
+                // (3) everything else: the plain form, one tile per workgroup.  8-byte values on the big tile come in two forms and the
+                // pass's skew flag picks one (BinCfg::VROUNDS); pairs that may run on position chains add that form as a launch of its own.
+                const bool two_forms = dyn && vb == 8 && !is_key64(kt) && sh.threads == 512 && sh.kpt == 32;
+                launch(p == 0 ? fn0 : fn, p == 0 ? plan.grid0 : plan.grid, p, a, word * 32 + p * 8,
+                       mode | (two_forms ? gs::BM_IF_EVEN : 0u) | ((pos && vb != 0) ? gs::BM_FORMS : 0u) | exp_mode);
+                if (two_forms) launch(g_vr2[h->rank_mode][kt], plan.grid, p, a, word * 32 + p * 8, mode | gs::BM_IF_SKEW | ((pos && vb == 8) ? gs::BM_FORMS : 0u));
+                if (pos && vb != 0) launch(g_posv[vb == 8][p == 3][kt], pos_grid(), p, a, p * 8, (mode & ~gs::BM_ZERO_HIST) | gs::BM_FORMS);
+            }
             if (h->profiling && word == 0 && p < 4 && !(hy && p == 1)) GS_HIP(hipEventRecord(h->ev[4 + p], s));
         }
     }

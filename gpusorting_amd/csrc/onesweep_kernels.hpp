@@ -987,6 +987,22 @@ constexpr uint32_t BM_INFO_CHAINS = 256;  // the chain count comes from the info
 constexpr uint32_t BM_ZERO_DESC23 = 512;  // LSD pass 1 of a sort that was offered the two-level plan: zeroes the descriptor regions of passes 2 and 3 if the LSD plan runs
 // (experiment builds, GS_EXP & 1024 / 2048, reuse bits 256 .. 2048 as run-time ablation switches of plain LSD launches: onesweep_ablation.hpp)
 
+// MAP of binning_body (one function on purpose: every phase works on the tile's keys in registers — key[KPT], the packed ranks
+// offp[], the per-digit prefix in LDS — and a split into functions would pass ~30 of them by reference; the compile-time switches
+// below prune each instantiation to the phases its kernel needs).  Phases, in order, with the switches that touch them:
+//   entry      launch-level duties and licences: BM_ZERO_HIST / BM_ZERO_DESC23 zeroing; BM_IF_* / BM_FORMS: does THIS form of the pass work?
+//   POS setup  (POS != 0) digit starts / skew / mode digit from CNEXT of the pass before; the workgroup's next-digit table
+//   [tile loop, PERSIST: until every chain is claimed]
+//   claim      ticket on the workgroup's chain (BM_INFO_CHAINS: chain groups of a CHMAX-chain pass), else steal from an open chain
+//   load       wave-striped key loads (KW == 2: 64-bit keys carry their other word along); partial tiles masked
+//   rank       RANK 0: eight-ballot multi-split; RANK 1: one returning LDS add per key (crowded waves: ballot + one add); PK: counters packed 2 x 16
+//   reduce     per-digit exclusive prefix over waves, tile total, REDUCTION row published, digit scan
+//   stage      keys to LDS in digit order (VR == 2: 8-byte values in two staging rounds)
+//   look-back  one digit per thread walks the chain's rows back to an INCLUSIVE one; GS_FALLBACK: recount a row nobody published
+//   values     (VB != 0) the tile's values fetched late and staged behind the keys
+//   count-next (POS == 1) the next pass's digit counted per output position segment while scattering; flushed to CNEXT at the end
+//   scatter    stage slot i -> global base of its digit + i (reverse: the descending rule on the plan's last pass), coalesced runs
+//   exit       (POS == 1) CNEXT flush; trace / fault hooks of experiment builds
 template <int THREADS, int KPT, int VB, int KT, int RANK, int VR, int POS, bool PERSIST>
 __device__ __forceinline__ void binning_body(
     unsigned char* s_raw,
