@@ -385,3 +385,43 @@ def test_two_level_plan_at_its_thresholds_and_class_borders(gpu, n, vb):
     assert bool((out[0][0] == out[1][0]).all().item())
     if vb:
         assert bool((out[0][1] == out[1][1]).all().item())
+
+
+@pytest.mark.parametrize("log2n,pairs", [(28, False), (27, True)])
+def test_sharded_pipeline_full_size_bucket_landed_bin_major_exact(gpu, oracle, log2n, pairs):
+    """BASELINE configs[3]'s per-GPU share (2^28 keys) through gs_onesweep_sort_sharded on ONE rank with the exchange forced, default
+    options: the bucket is offered the two-level plan, so it is landed in the alternate buffer and the local sort starts at the plan's
+    second pass (gs_mgpu_last_layout) — exact against the oracle; pairs at 2^27 with value = index (stability through split, landing
+    and the pre-grouped local sort)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gpusorting_amd.sharded import ShardedOneSweep
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        n = 1 << log2n
+        dk = torch.empty(n, dtype=torch.int32, device="cuda")
+        gpu.init_random(dk, 2800 + log2n, 0)
+        torch.cuda.synchronize()
+        keys = dk.cpu().numpy().view(np.uint32)
+        dv = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
+        s = ShardedOneSweep(n, pairs=pairs, value_bytes=4, always_exchange=True, slack=1.0)
+        bk, bv, nb = s.sort(dk, values=dv)
+        s.check()
+        assert nb == n and s.last_bin_major and s.engine.sorter.last_plan()["two_level"]
+        if pairs:
+            perm = torch.from_numpy(oracle.sort_permutation_parallel(keys, 0, 0).view(np.int32)).cuda()
+            assert bool((bv[:n] == perm).all().item()), "payload order differs from the stable sort"
+            assert bool((bk[:n] == dk[perm.to(torch.int64) & 0xFFFFFFFF]).all().item())
+        else:
+            ref = torch.from_numpy(oracle.std_sort_parallel(keys, oracle.hardware_threads()).view(np.int32)).cuda()
+            assert bool((bk[:n] == ref).all().item()), "sorted keys differ from the oracle"
+        s.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
