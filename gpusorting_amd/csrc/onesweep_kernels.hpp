@@ -987,20 +987,379 @@ constexpr uint32_t BM_INFO_CHAINS = 256;  // the chain count comes from the info
 constexpr uint32_t BM_ZERO_DESC23 = 512;  // LSD pass 1 of a sort that was offered the two-level plan: zeroes the descriptor regions of passes 2 and 3 if the LSD plan runs
 // (experiment builds, GS_EXP & 1024 / 2048, reuse bits 256 .. 2048 as run-time ablation switches of plain LSD launches: onesweep_ablation.hpp)
 
-// MAP of binning_body (one function on purpose: every phase works on the tile's keys in registers — key[KPT], the packed ranks
-// offp[], the per-digit prefix in LDS — and a split into functions would pass ~30 of them by reference; the compile-time switches
-// below prune each instantiation to the phases its kernel needs).  Phases, in order, with the switches that touch them:
-//   entry      launch-level duties and licences: BM_ZERO_HIST / BM_ZERO_DESC23 zeroing; BM_IF_* / BM_FORMS: does THIS form of the pass work?
+// ---------------------------------------------------------------------------
+// binning_body, phase "load": the tile's keys, wave-striped (lane l of wave w holds keys tile_base + 64 KPT w + 64 i + l: coalesced
+// 256 B per wave instruction, 512 B for 64-bit keys), in radix-sortable form.  key[] is the word that holds the pass's digit, key2[]
+// (64-bit keys) the other one, which just travels along.  A partial tile [lo, hi) masks the slots outside.
+// ---------------------------------------------------------------------------
+template <int KPT, int VB, int KT>
+__device__ __forceinline__ void bin_load_keys(const uint32_t* __restrict__ keys_in, const uint32_t my_base, const uint32_t lo, const uint32_t hi,
+                                               const bool full, const bool hi_word, uint32_t (&key)[KPT],
+                                               uint32_t (&key2)[KeyWords<KT>::value == 2 ? KPT : 1]) {
+    constexpr int KW = KeyWords<KT>::value;
+    if constexpr (KW == 2) {
+        const uint2* kin2 = reinterpret_cast<const uint2*>(keys_in);
+        uint2 raw[KPT];
+        if (GS_LIKELY(full)) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) raw[i] = ld_stream<VB == 0>(kin2 + my_base + i * 64u);
+        } else {  // unconditional loads on a clamped index, masked below (see the 32-bit form)
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = my_base + i * 64u;
+                raw[i] = ld_stream<VB == 0>(kin2 + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            const uint2 b = to_bits2<KT>(raw[i]);
+            key[i] = hi_word ? b.y : b.x;
+            key2[i] = hi_word ? b.x : b.y;
+            if (!full) key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : key[i]);
+        }
+    } else if (GS_LIKELY(full)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(ld_stream<VB == 0>(keys_in + my_base + i * 64u));
+    } else {
+        // Masked slots become dummy keys that are never written: in FRONT of the segment
+        // all-zero bits (digit 0: being first in array order they open the digit-0 run, stage
+        // slots [0, head)), BEHIND it all-one bits (digit 255: they close the last run).
+        // The loads are UNCONDITIONAL on a clamped index and masked afterwards: guarded loads are issued one
+        // at a time (a wait after each), which made every partial tile ~20 us — the whole pass at mid sizes,
+        // where each chain is one or two partial tiles.
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            key[i] = ld_stream<VB == 0>(keys_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : to_bits<KT>(key[i]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// binning_body, phase "rank": every key's rank among the keys of its digit inside this wave, two 16-bit ranks per register of offp[]
+// (later: tile-local positions); the wave's counters `whist` end up holding its digit counts.  RANK 0: the reference's ballot
+// multi-split (OneSweep.cu:207-253) for 64 lanes.  RANK 1: one returning LDS add per key — with the forms for crowded waves
+// (presorted input), partial tiles (the dummies behind the segment are not ranked) and skewed passes (the pass's most frequent digit
+// `skew_digit` never touches the LDS).  PK: two waves share a counter word, one 16-bit half each (`wsh` = this wave's shift).
+// ---------------------------------------------------------------------------
+template <int KPT, int RANK, bool PK>
+__device__ __forceinline__ void bin_rank_keys(const uint32_t (&key)[KPT], uint32_t (&offp)[KPT / 2], const uint32_t shift, uint32_t* __restrict__ whist,
+                                               const uint32_t wsh, const uint32_t pflags, const bool full, const uint32_t my_base, const uint32_t hi,
+                                               const uint32_t skew_digit, const uint32_t lane) {
+    if constexpr (RANK == 0) {
+        // Wave-level multi-split with 64-lane ballots: each lane finds its peers
+        // (lanes holding the same digit) with 8 ballots, ranks itself among them
+        // with mbcnt, and the LAST peer bumps the wave's private LDS counter.  LDS
+        // operations of one wave execute in issue order, so the plain read of round
+        // i+1 sees the write of round i; the asm clobber only pins the compiler.
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = (key[i] >> shift) & 255u;
+            uint32_t acc_lo = 0, acc_hi = 0;  // bit l set <=> lane l's digit differs from mine
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)key[i], shift + k, 1);  // 0 or ~0
+                const unsigned long long b = __builtin_amdgcn_ballot_w64(B != 0u);
+                acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (uint32_t)b, B, 0xF6);  // acc | (b ^ B)
+                acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (uint32_t)(b >> 32), B, 0xF6);
+            }
+            const uint32_t plo = ~acc_lo, phi = ~acc_hi;  // peers: lanes with my digit
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t total = __popc(plo) + __popc(phi);
+            const uint32_t pre = whist[d];                    // same value for all peers (LDS broadcast)
+            if (below == total - 1u) whist[d] = pre + total;  // last peer bumps the wave's counter
+            asm volatile("" ::: "memory");
+            offp[i >> 1] |= (pre + below) << (16 * (i & 1));
+        }
+    } else {
+        // One returning LDS atomic per key on the wave-private counter.  Correct only
+        // where the LDS hands same-address lanes of ONE wave-instruction their
+        // results in ascending lane order; gs_selftest_lds_atomic_order() probes
+        // exactly that on the device before this path is ever selected.
+      {
+        // one returning LDS add on the wave's counter of digit d
+        auto rank_add = [&](uint32_t d) -> uint32_t {
+            const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return PK ? (r >> wsh) & 0xffffu : r;
+        };
+        // Crowded waves: presorted or clustered input puts the SAME digit in most lanes of a wave (a sorted tile holds one or two
+        // values of every byte above its own span) although no digit dominates the pass as a whole (PF_SKEW is clear) — and 64
+        // lanes on one LDS counter are served one after the other: 1.10 ms per pass on sorted keys against 0.43 (profiles/
+        // r05_sorted_inputs.txt).  One probe per wave and tile (its first and its last key round): a wave that finds >= 16 lanes on
+        // the first lane's digit ranks the whole tile with the first lane's digit aggregated — those lanes take ballot ranks on top of
+        // ONE add of their count by their first lane, every other lane adds for itself in the same instruction (different
+        // counters: nothing changes for them, and ranks stay in lane order, i.e. stable).
+        bool crowded = false;  // wave-uniform
+        if ((pflags & PF_SKEW) == 0u && full) {
+            const uint32_t da = (key[0] >> shift) & 255u, db = (key[KPT - 1] >> shift) & 255u;
+            crowded = __popcll(__builtin_amdgcn_ballot_w64(da == (uint32_t)__builtin_amdgcn_readfirstlane((int)da))) >= 16 ||
+                      __popcll(__builtin_amdgcn_ballot_w64(db == (uint32_t)__builtin_amdgcn_readfirstlane((int)db))) >= 16;
+        }
+        if (GS_LIKELY((pflags & PF_SKEW) == 0u && full && !crowded)) {  // uniform per pass (set by scan_kernel)
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t r = rank_add(d);
+                offp[i >> 1] |= r << (16 * (i & 1));
+            }
+        } else if ((pflags & PF_SKEW) == 0u && full) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(d == f);  // (lane 0 is in it)
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const bool in_m = d == f;
+                uint32_t r = 0;
+                if (!in_m || below == 0u) {
+                    const uint32_t inc = in_m ? (uint32_t)__popcll(m) : 1u;
+                    const uint32_t w = __hip_atomic_fetch_add(&whist[d], inc << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    r = PK ? (w >> wsh) & 0xffffu : w;
+                }
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(m));
+                offp[i >> 1] |= (in_m ? base + below : r) << (16 * (i & 1));
+            }
+        } else if ((pflags & PF_SKEW) == 0u) {
+            // Partial tile: the dummies behind the segment take no part at all (mask_tail below).  Ranked like
+            // keys they would put up to 64 lanes x KPT rounds on the single counter of digit 255 — ~12 us, on
+            // the last tile of every chain: the tail of every pass, and most of a pass at mid sizes.
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                if (my_base + i * 64u < hi) {
+                    const uint32_t d = (key[i] >> shift) & 255u;
+                    const uint32_t r = rank_add(d);
+                    offp[i >> 1] |= r << (16 * (i & 1));
+                }
+            }
+        } else {
+            // Skewed pass: the keys holding the pass's MOST FREQUENT digit value (known to scan_kernel from the
+            // histogram: I_MODE, the same for every wave of the pass) never touch the LDS — their rank is the wave's
+            // running count of such keys (a scalar) plus mbcnt of one ballot, and the counter of that digit, which
+            // nobody else adds to, is written once at the end.  All other lanes add 1 for themselves in the same
+            // round.  Nothing depends on a returned value, so the atomics of a chunk are issued back to back.
+            // (The earlier form learned the dominant digit per wave while ranking — ballots, a relearn branch and a
+            // leader election per key: load + rank 6.6 us per 16 384-key tile at entropy preset 3 against 3.3 us now and
+            // 2.4 us for uniform keys, profiles/r02_skew_rank_fixed_mode.txt.)
+            constexpr int SKEW_CHUNK = KPT % 8 == 0 ? 8 : 4;
+            static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
+            const uint32_t sd = skew_digit;  // wave-uniform (scan_kernel's I_MODE, or the position-chain plan's mode digit)
+            uint32_t run = 0;  // wave-uniform: keys of digit sd in this wave so far
+#pragma unroll
+            for (int c = 0; c < KPT; c += SKEW_CHUNK) {
+                uint32_t ret[SKEW_CHUNK];
+#pragma unroll
+                for (int j = 0; j < SKEW_CHUNK; ++j) {
+                    const uint32_t d = (key[c + j] >> shift) & 255u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(d == sd);
+                    ret[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
+                    run += (uint32_t)__popcll(m);
+                    // (PK: the counter's WORD comes back; the wave's half is taken out below, outside the branch — inside, every
+                    //  add waited for its own return before the next one was issued.  The other lanes' ranks go through the same
+                    //  extraction: they are shifted into the half here.)
+                    if constexpr (PK) ret[j] <<= wsh;
+                    if (d != sd) ret[j] = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int j = 0; j < SKEW_CHUNK; ++j) {
+                    const int i = c + j;
+                    if constexpr (PK) ret[j] = (ret[j] >> wsh) & 0xffffu;
+                    if (i & 1) offp[i >> 1] |= ret[j] << 16; else offp[i >> 1] |= ret[j];
+                }
+            }
+            if (lane == 0 && sd < RADIX) {
+                if constexpr (PK) atomicAdd(&whist[sd], run << wsh);  // (nobody of this wave added to its half; the other half is the neighbour wave's)
+                else whist[sd] = run;
+            }
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// binning_body, phase "claim", second half: the workgroup's own chain is fully claimed — take a tile of ANOTHER chain that still has
+// unclaimed tiles.  Leaves the chain in s_misc[0] and the ticket in s_misc[1] (~0: every chain is fully claimed); the caller reads
+// them behind a barrier.  `chain` = the chain just found exhausted (the linear search starts behind it).
+// ---------------------------------------------------------------------------
+template <uint32_t THREADS, uint32_t TILE>
+__device__ __forceinline__ void bin_steal_tile(const uint32_t nch, const uint32_t chain, const uint32_t* __restrict__ info, uint32_t* __restrict__ counters,
+                                                uint32_t* __restrict__ s_misc) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
+    // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
+    __syncthreads();
+    if (nch > 64u) {
+        // More chains than a wave has lanes (the two-level plan's second pass: CHMAX chains, THREADS >= CHMAX): thread x looks at
+        // chain x; the open chain nearest to a per-workgroup starting point (Fibonacci hashing of the workgroup id: stealers
+        // spread over the open chains) is tried with one ticket, until a ticket holds or no chain is open.
+        const uint32_t start = ((blockIdx.x * 0x9E3779B1u) >> 16) & (nch - 1u);
+        for (;;) {
+            if (tid == 0) s_misc[0] = 0xffffffffu;
+            __syncthreads();
+            if (tid < nch) {
+                const uint32_t tx = chain_tiles(info[I_START + tid], info[I_END + tid], TILE);
+                if (ld_agent(&counters[tid * COUNTER_STRIDE]) < tx) atomicMin(&s_misc[0], (((tid - start) & (nch - 1u)) << 16) | tid);
+            }
+            __syncthreads();
+            const uint32_t cand = uni(s_misc[0]);
+            if (cand == 0xffffffffu) {  // every chain is fully claimed
+                if (tid == 0) s_misc[1] = 0xffffffffu;
+                break;
+            }
+            const uint32_t x = cand & 0xffffu;
+            if (tid == 0) {
+                const uint32_t t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                s_misc[1] = t < chain_tiles(info[I_START + x], info[I_END + x], TILE) ? t : 0xffffffffu;
+            }
+            __syncthreads();
+            if (uni(s_misc[1]) != 0xffffffffu) {
+                if (tid == 0) s_misc[0] = x;
+                break;
+            }
+        }
+    } else if (wave == 0) {
+        uint32_t tiles_x = 0;
+        bool open = false;
+        if (lane < nch) {
+            tiles_x = chain_tiles(info[I_START + lane], info[I_END + lane], TILE);
+            open = ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(open);
+        uint32_t got_x = 0, got_t = 0xffffffffu;
+        // First try: a chain drawn in proportion to the chains' tile counts (Fibonacci hashing of the
+        // workgroup id: consecutive ids spread evenly over the cumulative tile range).  With skewed
+        // digit groups most workgroups land here — their own chain is tiny — and the big chains still
+        // get their workgroups interleaved, in one atomic instead of a scan of the open chains.
+        if (m) {
+            const uint32_t incl = wave_inclusive_scan(tiles_x, lane);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            const uint32_t v = (uint32_t)(((unsigned long long)(blockIdx.x * 0x9E3779B1u) * total) >> 32);
+            const unsigned long long ge = __builtin_amdgcn_ballot_w64(lane < nch && incl > v);
+            const uint32_t x = ge ? (uint32_t)__builtin_ctzll(ge) : 0u;
+            if ((m >> x) & 1ull) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t < __builtin_amdgcn_readlane(tiles_x, x)) { got_x = x; got_t = t; m = 0; }
+                else m &= ~(1ull << x);
+            }
+        }
+        while (m) {  // wave-uniform: try the open chains one by one, starting after our own
+            const unsigned long long above = m & ~((2ull << chain) - 1ull);  // chain < NCH <= 32
+            const uint32_t x = (uint32_t)__builtin_ctzll(above ? above : m);
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t tx = __builtin_amdgcn_readlane(tiles_x, x);
+            if (t < tx) { got_x = x; got_t = t; break; }
+            m &= ~(1ull << x);
+        }
+        if (lane == 0) { s_misc[0] = got_x; s_misc[1] = got_t; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// binning_body, phase "values": the tile's values in the keys' wave-striped arrangement — at the start of the tile for the fused
+// forms, late (the key registers are dead by then and the loads fly while the keys are scattered) for the others.  Clamped,
+// unconditional loads on a partial tile (see the key loads); slots outside [lo, hi) are never written out.
+// ---------------------------------------------------------------------------
+template <int KPT, typename V>
+__device__ __forceinline__ void bin_load_values(const V* __restrict__ vals_in, const uint32_t my_base, const uint32_t lo, const uint32_t hi, const bool full,
+                                                 V (&val)[KPT]) {
+    if (GS_LIKELY(full)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = my_base + i * 64u;
+            val[i] = ld_stream<false>(vals_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// binning_body, phase "count-next" (POS == 1), once per workgroup: the next-pass digit this workgroup does NOT count while it scatters
+// (its counts are recovered at the flush from the keys written per segment).  Every wave looks at 64 staged keys of its own (`mine` =
+// this lane's), eight candidate lanes each; a digit that at least 8 of the 64 share is a find, the most frequent find wins
+// (s_pos[5] = (popcount << 8) | digit) and becomes s_pos[4]; without a find the choice is left to the next tile.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bin_elect_left_out_digit(const uint32_t* __restrict__ mine, const uint32_t next_shift, uint32_t* __restrict__ s_pos) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    __syncthreads();  // (everybody has read s_pos[4])
+    {
+        const uint32_t d0 = (*mine >> next_shift) & 255u;
+        uint32_t best = 0;  // (popcount << 8) | digit
+#pragma unroll
+        for (int c = 0; c < 64; c += 8) {
+            const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)d0, c);
+            const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d0 == cand));
+            best = ((pc << 8) | cand) > best ? ((pc << 8) | cand) : best;
+        }
+        if (lane == 0 && (best >> 8) >= 8u) atomicMax(&s_pos[5], best);
+    }
+    __syncthreads();
+    if (tid == 0 && s_pos[5] != 0u) s_pos[4] = s_pos[5] & 255u;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// binning_body, phase "entry": what a LAUNCH owes the sort whatever its tiles do — BM_ZERO_HIST: the first pass launched after the Scan
+// hands the HIST region back zeroed (see global_histogram_kernel); BM_ZERO_DESC23: LSD pass 1 of a sort that was offered the two-level
+// plan zeroes the descriptor regions of passes 2 and 3 if the LSD plan runs — and the licences: a pass launched in several forms
+// (BM_IF_SKEW / BM_IF_EVEN: the two forms of the 8-byte-value pass; BM_FORMS: plain and position-chain form) works in exactly one of
+// them, the one the pass's flag word (PF_SKEW, PF_POS: decided on the device) names.  Returns false for the others.
+// ---------------------------------------------------------------------------
+template <uint32_t THREADS, int POS>
+__device__ __forceinline__ bool bin_entry(const uint32_t mode, const uint32_t* __restrict__ info, uint32_t* __restrict__ desc, uint32_t* __restrict__ hsub) {
+    const uint32_t tid = threadIdx.x;
+    if (mode & BM_ZERO_HIST) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
+        // (grid-stride: a small grid of a 256-thread tuning shape does not cover the 8200 16-byte words with one store per thread)
+        for (uint32_t i = blockIdx.x * THREADS + tid; i < HIST_WORDS / 4; i += gridDim.x * THREADS)
+            reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
+    }
+    if (mode & BM_ZERO_DESC23) {
+        // A sort that was offered the two-level plan and runs on the LSD passes after all (PF_POS is set): the histogram kernel zeroed
+        // only the descriptor regions both plans use (passes 0 and 1); this launch — LSD pass 1 — zeroes the regions of passes 2 and 3
+        // beside its own work (they lie behind its own region; nobody touches them before pass 2 starts).
+        if (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) {
+            const uint32_t stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_DSTRIDE]);
+            uint4* z = reinterpret_cast<uint4*>(desc + stride);
+            for (uint32_t i = blockIdx.x * THREADS + tid; i < stride / 2u; i += gridDim.x * THREADS) z[i] = uint4{0u, 0u, 0u, 0u};  // 2 x stride words
+        }
+    }
+    if (mode & (BM_IF_SKEW | BM_IF_EVEN)) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
+        const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
+        if (skewed != ((mode & BM_IF_SKEW) != 0u)) return false;
+    }
+    if (mode & BM_FORMS) {  // the pass is launched in several forms: the plan says whether the position-chain form or the others work
+        const bool planned_pos = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) != 0;
+        if (planned_pos != (POS != 0)) return false;
+    }
+    return true;
+}
+
+// MAP of binning_body.  The phases with a narrow interface are functions of their own above (bin_entry, bin_steal_tile, bin_load_keys,
+// bin_load_values, bin_rank_keys, bin_elect_left_out_digit: round 6); what is left in the body works on the tile's state all at once —
+// key[KPT], the packed ranks offp[], the per-digit prefixes and bases in LDS, the chain's descriptor rows — and would pass ~30 of them
+// by reference.  The compile-time switches prune each instantiation to the phases its kernel needs.  Phases, in order:
+//   entry      bin_entry: BM_ZERO_HIST / BM_ZERO_DESC23 zeroing; BM_IF_* / BM_FORMS: does THIS form of the pass work?
 //   POS setup  (POS != 0) digit starts / skew / mode digit from CNEXT of the pass before; the workgroup's next-digit table
 //   [tile loop, PERSIST: until every chain is claimed]
-//   claim      ticket on the workgroup's chain (BM_INFO_CHAINS: chain groups of a CHMAX-chain pass), else steal from an open chain
-//   load       wave-striped key loads (KW == 2: 64-bit keys carry their other word along); partial tiles masked
-//   rank       RANK 0: eight-ballot multi-split; RANK 1: one returning LDS add per key (crowded waves: ballot + one add); PK: counters packed 2 x 16
+//   claim      ticket on the workgroup's chain (BM_INFO_CHAINS: chain groups of a CHMAX-chain pass), else bin_steal_tile
+//   load       bin_load_keys (KW == 2: 64-bit keys carry their other word along); partial tiles masked; fused forms: bin_load_values
+//   rank       bin_rank_keys — RANK 0: eight-ballot multi-split; RANK 1: one returning LDS add per key (crowded waves, partial tiles, skew)
 //   reduce     per-digit exclusive prefix over waves, tile total, REDUCTION row published, digit scan
 //   stage      keys to LDS in digit order (VR == 2: 8-byte values in two staging rounds)
 //   look-back  one digit per thread walks the chain's rows back to an INCLUSIVE one; GS_FALLBACK: recount a row nobody published
-//   values     (VB != 0) the tile's values fetched late and staged behind the keys
-//   count-next (POS == 1) the next pass's digit counted per output position segment while scattering; flushed to CNEXT at the end
+//   values     (VB != 0, not fused) bin_load_values: fetched late, staged behind the keys
+//   count-next (POS == 1) bin_elect_left_out_digit once; the next pass's digit counted per output position segment while scattering
 //   scatter    stage slot i -> global base of its digit + i (reverse: the descending rule on the plan's last pass), coalesced runs
 //   exit       (POS == 1) CNEXT flush; trace / fault hooks of experiment builds
 template <int THREADS, int KPT, int VB, int KT, int RANK, int VR, int POS, bool PERSIST>
@@ -1060,29 +1419,7 @@ __device__ __forceinline__ void binning_body(
                                                            // POS == 1: [4] the next digit this workgroup does NOT count (see count_next), [5] its election, [8..23] keys written per output segment
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    if (mode & BM_ZERO_HIST) {  // first pass launched after the Scan: hand the HIST region back zeroed (see global_histogram_kernel)
-        // (grid-stride: a small grid of a 256-thread tuning shape does not cover the 8200 16-byte words with one store per thread)
-        for (uint32_t i = blockIdx.x * THREADS + tid; i < HIST_WORDS / 4; i += gridDim.x * THREADS)
-            reinterpret_cast<uint4*>(hsub - HIST_WORDS)[i] = uint4{0u, 0u, 0u, 0u};
-    }
-    if (mode & BM_ZERO_DESC23) {
-        // A sort that was offered the two-level plan and runs on the LSD passes after all (PF_POS is set): the histogram kernel zeroed
-        // only the descriptor regions both plans use (passes 0 and 1); this launch — LSD pass 1 — zeroes the regions of passes 2 and 3
-        // beside its own work (they lie behind its own region; nobody touches them before pass 2 starts).
-        if (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) {
-            const uint32_t stride = (uint32_t)__builtin_amdgcn_readfirstlane((int)info[I_DSTRIDE]);
-            uint4* z = reinterpret_cast<uint4*>(desc + stride);
-            for (uint32_t i = blockIdx.x * THREADS + tid; i < stride / 2u; i += gridDim.x * THREADS) z[i] = uint4{0u, 0u, 0u, 0u};  // 2 x stride words
-        }
-    }
-    if (mode & (BM_IF_SKEW | BM_IF_EVEN)) {  // one of two launches of this pass: the flag word says which one works (before any ticket is drawn)
-        const bool skewed = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_SKEW) != 0;
-        if (skewed != ((mode & BM_IF_SKEW) != 0u)) return;
-    }
-    if (mode & BM_FORMS) {  // the pass is launched in several forms: the plan says whether the position-chain form or the others work
-        const bool planned_pos = (__builtin_amdgcn_readfirstlane((int)info[PASS_FLAGS]) & (int)PF_POS) != 0;
-        if (planned_pos != (POS != 0)) return;
-    }
+    if (!bin_entry<(uint32_t)THREADS, POS>(mode, info, desc, hsub)) return;  // launch-level duties; is this form of the pass the one that works?
     // ---- POS: what a workgroup of a position-chain pass sets up once.  Behind the first pass nobody knows the pass's digit
     // counts upfront: CNEXT[this pass][segment][digit], gathered by the pass that wrote this pass's input, is all there
     // is — every workgroup derives the digit starts (s_dstart), whether the pass is skewed and its most frequent digit
@@ -1204,77 +1541,7 @@ __device__ __forceinline__ void binning_body(
                 continue;
             }
         }
-        // Steal: wave 0 looks at ALL chains in one parallel round trip (lane x = chain x); a serial
-        // scan with dependent sc1 loads cost ~22 us per exhausted workgroup and stretched every pass's tail.
-        __syncthreads();
-        if (nch > 64u) {
-            // More chains than a wave has lanes (the two-level plan's second pass: CHMAX chains, THREADS >= CHMAX): thread x looks at
-            // chain x; the open chain nearest to a per-workgroup starting point (Fibonacci hashing of the workgroup id: stealers
-            // spread over the open chains) is tried with one ticket, until a ticket holds or no chain is open.
-            const uint32_t start = ((blockIdx.x * 0x9E3779B1u) >> 16) & (nch - 1u);
-            for (;;) {
-                if (tid == 0) s_misc[0] = 0xffffffffu;
-                __syncthreads();
-                if (tid < nch) {
-                    const uint32_t tx = chain_tiles(info[I_START + tid], info[I_END + tid], TILE);
-                    if (ld_agent(&counters[tid * COUNTER_STRIDE]) < tx) atomicMin(&s_misc[0], (((tid - start) & (nch - 1u)) << 16) | tid);
-                }
-                __syncthreads();
-                const uint32_t cand = uni(s_misc[0]);
-                if (cand == 0xffffffffu) {  // every chain is fully claimed
-                    if (tid == 0) s_misc[1] = 0xffffffffu;
-                    break;
-                }
-                const uint32_t x = cand & 0xffffu;
-                if (tid == 0) {
-                    const uint32_t t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
-                    s_misc[1] = t < chain_tiles(info[I_START + x], info[I_END + x], TILE) ? t : 0xffffffffu;
-                }
-                __syncthreads();
-                if (uni(s_misc[1]) != 0xffffffffu) {
-                    if (tid == 0) s_misc[0] = x;
-                    break;
-                }
-            }
-        } else if (wave == 0) {
-            uint32_t tiles_x = 0;
-            bool open = false;
-            if (lane < nch) {
-                tiles_x = chain_tiles(info[I_START + lane], info[I_END + lane], TILE);
-                open = ld_agent(&counters[lane * COUNTER_STRIDE]) < tiles_x;
-            }
-            unsigned long long m = __builtin_amdgcn_ballot_w64(open);
-            uint32_t got_x = 0, got_t = 0xffffffffu;
-            // First try: a chain drawn in proportion to the chains' tile counts (Fibonacci hashing of the
-            // workgroup id: consecutive ids spread evenly over the cumulative tile range).  With skewed
-            // digit groups most workgroups land here — their own chain is tiny — and the big chains still
-            // get their workgroups interleaved, in one atomic instead of a scan of the open chains.
-            if (m) {
-                const uint32_t incl = wave_inclusive_scan(tiles_x, lane);
-                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t v = (uint32_t)(((unsigned long long)(blockIdx.x * 0x9E3779B1u) * total) >> 32);
-                const unsigned long long ge = __builtin_amdgcn_ballot_w64(lane < nch && incl > v);
-                const uint32_t x = ge ? (uint32_t)__builtin_ctzll(ge) : 0u;
-                if ((m >> x) & 1ull) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
-                    t = __builtin_amdgcn_readfirstlane(t);
-                    if (t < __builtin_amdgcn_readlane(tiles_x, x)) { got_x = x; got_t = t; m = 0; }
-                    else m &= ~(1ull << x);
-                }
-            }
-            while (m) {  // wave-uniform: try the open chains one by one, starting after our own
-                const unsigned long long above = m & ~((2ull << chain) - 1ull);  // chain < NCH <= 32
-                const uint32_t x = (uint32_t)__builtin_ctzll(above ? above : m);
-                uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(&counters[x * COUNTER_STRIDE], 1u);
-                t = __builtin_amdgcn_readfirstlane(t);
-                const uint32_t tx = __builtin_amdgcn_readlane(tiles_x, x);
-                if (t < tx) { got_x = x; got_t = t; break; }
-                m &= ~(1ull << x);
-            }
-            if (lane == 0) { s_misc[0] = got_x; s_misc[1] = got_t; }
-        }
+        bin_steal_tile<(uint32_t)THREADS, TILE>(nch, chain, info, counters, s_misc);
         __syncthreads();
         chain = uni(s_misc[0]);
         tile = uni(s_misc[1]);
@@ -1307,63 +1574,10 @@ __device__ __forceinline__ void binning_body(
     uint32_t key[KPT];
     uint32_t key2[KW == 2 ? KPT : 1];
     const uint32_t my_base = tile_base + wave * (64u * KPT) + lane;
-    if constexpr (KW == 2) {
-        const uint2* kin2 = reinterpret_cast<const uint2*>(keys_in);
-        uint2 raw[KPT];
-        if (GS_LIKELY(full)) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) raw[i] = ld_stream<VB == 0>(kin2 + my_base + i * 64u);
-        } else {  // unconditional loads on a clamped index, masked below (see the 32-bit form)
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t idx = my_base + i * 64u;
-                raw[i] = ld_stream<VB == 0>(kin2 + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = my_base + i * 64u;
-            const uint2 b = to_bits2<KT>(raw[i]);
-            key[i] = hi_word ? b.y : b.x;
-            key2[i] = hi_word ? b.x : b.y;
-            if (!full) key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : key[i]);
-        }
-    } else if (GS_LIKELY(full)) {
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) key[i] = to_bits<KT>(ld_stream<VB == 0>(keys_in + my_base + i * 64u));
-    } else {
-        // Masked slots become dummy keys that are never written: in FRONT of the segment
-        // all-zero bits (digit 0: being first in array order they open the digit-0 run, stage
-        // slots [0, head)), BEHIND it all-one bits (digit 255: they close the last run).
-        // The loads are UNCONDITIONAL on a clamped index and masked afterwards: guarded loads are issued one
-        // at a time (a wait after each), which made every partial tile ~20 us — the whole pass at mid sizes,
-        // where each chain is one or two partial tiles.
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = my_base + i * 64u;
-            key[i] = ld_stream<VB == 0>(keys_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
-        }
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = my_base + i * 64u;
-            key[i] = idx < lo ? 0u : (idx >= hi ? 0xffffffffu : to_bits<KT>(key[i]));
-        }
-    }
+    bin_load_keys<KPT, VB, KT>(keys_in, my_base, lo, hi, full, hi_word, key, key2);
 
     V val[VB != 0 ? KPT : 1];
-    if constexpr (Cfg::FUSED) {  // the values come along from the start
-        const V* vals_in = reinterpret_cast<const V*>(vals_in_);
-        if (GS_LIKELY(full)) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
-        } else {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t idx = my_base + i * 64u;
-                val[i] = ld_stream<false>(vals_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
-            }
-        }
-    }
+    if constexpr (Cfg::FUSED) bin_load_values<KPT, V>(reinterpret_cast<const V*>(vals_in_), my_base, lo, hi, full, val);  // the values come along from the start
 
     // ---- rank every key among the keys of its digit inside this wave ----
     // offp[] holds two 16-bit ranks (later: tile-local positions) per register.
@@ -1377,133 +1591,8 @@ __device__ __forceinline__ void binning_body(
     uint32_t offp[KPT / 2];
 #pragma unroll
     for (int i = 0; i < KPT / 2; ++i) offp[i] = 0;
-    if constexpr (RANK == 0) {
-        // Wave-level multi-split with 64-lane ballots: each lane finds its peers
-        // (lanes holding the same digit) with 8 ballots, ranks itself among them
-        // with mbcnt, and the LAST peer bumps the wave's private LDS counter.  LDS
-        // operations of one wave execute in issue order, so the plain read of round
-        // i+1 sees the write of round i; the asm clobber only pins the compiler.
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t d = (key[i] >> shift) & 255u;
-            uint32_t acc_lo = 0, acc_hi = 0;  // bit l set <=> lane l's digit differs from mine
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t B = (uint32_t)__builtin_amdgcn_sbfe((int32_t)key[i], shift + k, 1);  // 0 or ~0
-                const unsigned long long b = __builtin_amdgcn_ballot_w64(B != 0u);
-                acc_lo = __builtin_amdgcn_bitop3_b32(acc_lo, (uint32_t)b, B, 0xF6);  // acc | (b ^ B)
-                acc_hi = __builtin_amdgcn_bitop3_b32(acc_hi, (uint32_t)(b >> 32), B, 0xF6);
-            }
-            const uint32_t plo = ~acc_lo, phi = ~acc_hi;  // peers: lanes with my digit
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-            const uint32_t total = __popc(plo) + __popc(phi);
-            const uint32_t pre = whist[d];                    // same value for all peers (LDS broadcast)
-            if (below == total - 1u) whist[d] = pre + total;  // last peer bumps the wave's counter
-            asm volatile("" ::: "memory");
-            offp[i >> 1] |= (pre + below) << (16 * (i & 1));
-        }
-    } else {
-        // One returning LDS atomic per key on the wave-private counter.  Correct only
-        // where the LDS hands same-address lanes of ONE wave-instruction their
-        // results in ascending lane order; gs_selftest_lds_atomic_order() probes
-        // exactly that on the device before this path is ever selected.
-      {
-        // one returning LDS add on the wave's counter of digit d
-        auto rank_add = [&](uint32_t d) -> uint32_t {
-            const uint32_t r = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return PK ? (r >> wsh) & 0xffffu : r;
-        };
-        // Crowded waves: presorted or clustered input puts the SAME digit in most lanes of a wave (a sorted tile holds one or two
-        // values of every byte above its own span) although no digit dominates the pass as a whole (PF_SKEW is clear) — and 64
-        // lanes on one LDS counter are served one after the other: 1.10 ms per pass on sorted keys against 0.43 (profiles/
-        // r05_sorted_inputs.txt).  One probe per wave and tile (its first and its last key round): a wave that finds >= 16 lanes on
-        // the first lane's digit ranks the whole tile with the first lane's digit aggregated — those lanes take ballot ranks on top of
-        // ONE add of their count by their first lane, every other lane adds for itself in the same instruction (different
-        // counters: nothing changes for them, and ranks stay in lane order, i.e. stable).
-        bool crowded = false;  // wave-uniform
-        if ((pflags & PF_SKEW) == 0u && full) {
-            const uint32_t da = (key[0] >> shift) & 255u, db = (key[KPT - 1] >> shift) & 255u;
-            crowded = __popcll(__builtin_amdgcn_ballot_w64(da == (uint32_t)__builtin_amdgcn_readfirstlane((int)da))) >= 16 ||
-                      __popcll(__builtin_amdgcn_ballot_w64(db == (uint32_t)__builtin_amdgcn_readfirstlane((int)db))) >= 16;
-        }
-        if (GS_LIKELY((pflags & PF_SKEW) == 0u && full && !crowded)) {  // uniform per pass (set by scan_kernel)
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
-                const uint32_t r = rank_add(d);
-                offp[i >> 1] |= r << (16 * (i & 1));
-            }
-        } else if ((pflags & PF_SKEW) == 0u && full) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(d == f);  // (lane 0 is in it)
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const bool in_m = d == f;
-                uint32_t r = 0;
-                if (!in_m || below == 0u) {
-                    const uint32_t inc = in_m ? (uint32_t)__popcll(m) : 1u;
-                    const uint32_t w = __hip_atomic_fetch_add(&whist[d], inc << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    r = PK ? (w >> wsh) & 0xffffu : w;
-                }
-                const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)__builtin_ctzll(m));
-                offp[i >> 1] |= (in_m ? base + below : r) << (16 * (i & 1));
-            }
-        } else if ((pflags & PF_SKEW) == 0u) {
-            // Partial tile: the dummies behind the segment take no part at all (mask_tail below).  Ranked like
-            // keys they would put up to 64 lanes x KPT rounds on the single counter of digit 255 — ~12 us, on
-            // the last tile of every chain: the tail of every pass, and most of a pass at mid sizes.
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                if (my_base + i * 64u < hi) {
-                    const uint32_t d = (key[i] >> shift) & 255u;
-                    const uint32_t r = rank_add(d);
-                    offp[i >> 1] |= r << (16 * (i & 1));
-                }
-            }
-        } else {
-            // Skewed pass: the keys holding the pass's MOST FREQUENT digit value (known to scan_kernel from the
-            // histogram: I_MODE, the same for every wave of the pass) never touch the LDS — their rank is the wave's
-            // running count of such keys (a scalar) plus mbcnt of one ballot, and the counter of that digit, which
-            // nobody else adds to, is written once at the end.  All other lanes add 1 for themselves in the same
-            // round.  Nothing depends on a returned value, so the atomics of a chunk are issued back to back.
-            // (The earlier form learned the dominant digit per wave while ranking — ballots, a relearn branch and a
-            // leader election per key: load + rank 6.6 us per 16 384-key tile at entropy preset 3 against 3.3 us now and
-            // 2.4 us for uniform keys, profiles/r02_skew_rank_fixed_mode.txt.)
-            constexpr int SKEW_CHUNK = KPT % 8 == 0 ? 8 : 4;
-            static_assert(KPT % SKEW_CHUNK == 0, "KPT must be a multiple of the skew chunk");
-            const uint32_t sd = pos_derived ? pos_mode : uni(s_misc[15]);
-            uint32_t run = 0;  // wave-uniform: keys of digit sd in this wave so far
-#pragma unroll
-            for (int c = 0; c < KPT; c += SKEW_CHUNK) {
-                uint32_t ret[SKEW_CHUNK];
-#pragma unroll
-                for (int j = 0; j < SKEW_CHUNK; ++j) {
-                    const uint32_t d = (key[c + j] >> shift) & 255u;
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(d == sd);
-                    ret[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
-                    run += (uint32_t)__popcll(m);
-                    // (PK: the counter's WORD comes back; the wave's half is taken out below, outside the branch — inside, every
-                    //  add waited for its own return before the next one was issued.  The other lanes' ranks go through the same
-                    //  extraction: they are shifted into the half here.)
-                    if constexpr (PK) ret[j] <<= wsh;
-                    if (d != sd) ret[j] = __hip_atomic_fetch_add(&whist[d], 1u << wsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-#pragma unroll
-                for (int j = 0; j < SKEW_CHUNK; ++j) {
-                    const int i = c + j;
-                    if constexpr (PK) ret[j] = (ret[j] >> wsh) & 0xffffu;
-                    if (i & 1) offp[i >> 1] |= ret[j] << 16; else offp[i >> 1] |= ret[j];
-                }
-            }
-            if (lane == 0 && sd < RADIX) {
-                if constexpr (PK) atomicAdd(&whist[sd], run << wsh);  // (nobody of this wave added to its half; the other half is the neighbour wave's)
-                else whist[sd] = run;
-            }
-        }
-      }
-    }
+    bin_rank_keys<KPT, RANK, PK>(key, offp, shift, whist, wsh, pflags, full, my_base, hi,
+                                 ((pflags & PF_SKEW) != 0u) ? (pos_derived ? pos_mode : uni(s_misc[15])) : 0u, lane);
     GS_TRACE(2);
     __syncthreads();
 
@@ -1727,19 +1816,7 @@ __device__ __forceinline__ void binning_body(
 
     // ---- (pairs) fetch this tile's values now: the key registers are dead, and the loads fly
     // while the keys are scattered ----
-    if constexpr (VB != 0 && !Cfg::FUSED) {
-        const V* vals_in = reinterpret_cast<const V*>(vals_in_);
-        if (GS_LIKELY(full)) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) val[i] = ld_stream<false>(vals_in + my_base + i * 64u);
-        } else {  // clamped, unconditional (see the key loads); slots outside [lo, hi) are never written out
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t idx = my_base + i * 64u;
-                val[i] = ld_stream<false>(vals_in + (idx < lo ? lo : (idx >= hi ? hi - 1u : idx)));
-            }
-        }
-    }
+    if constexpr (VB != 0 && !Cfg::FUSED) bin_load_values<KPT, V>(reinterpret_cast<const V*>(vals_in_), my_base, lo, hi, full, val);
 
     // ---- POS: count the next pass's digit per output position segment while scattering.  One LDS add per key on the
     // workgroup's table [segment][digit] (flushed once, when the workgroup runs out of tiles); the stage is ordered by
@@ -1772,23 +1849,7 @@ __device__ __forceinline__ void binning_body(
         if (counting) {
             // the digit this workgroup leaves out, chosen ONCE: a next digit that at least 8 of 64 staged keys share (every wave looks at 64
             // of its own, eight candidate lanes each; the most frequent find wins); a tile without such a digit leaves the choice to the next one
-            if (uni(s_pos[4]) == 0xfffffffeu) {
-                __syncthreads();  // (everybody has read the word)
-                {
-                    const uint32_t d0 = (s_stage[wave * (TILE / WAVES) + lane] >> (next_shift & 31u)) & 255u;
-                    uint32_t best = 0;  // (popcount << 8) | digit
-#pragma unroll
-                    for (int c = 0; c < 64; c += 8) {
-                        const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)d0, c);
-                        const uint32_t pc = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d0 == cand));
-                        best = ((pc << 8) | cand) > best ? ((pc << 8) | cand) : best;
-                    }
-                    if (lane == 0 && (best >> 8) >= 8u) atomicMax(&s_pos[5], best);
-                }
-                __syncthreads();
-                if (tid == 0 && s_pos[5] != 0u) s_pos[4] = s_pos[5] & 255u;
-                __syncthreads();
-            }
+            if (uni(s_pos[4]) == 0xfffffffeu) bin_elect_left_out_digit(s_stage + wave * (TILE / WAVES) + lane, next_shift & 31u, s_pos);
             cnt_guess = uni(s_pos[4]);
             if (cnt_guess == 0xfffffffeu) cnt_guess = 0xffffffffu;  // (no digit left out in this tile: nothing to recover for it)
         }
