@@ -537,9 +537,21 @@ gs_status gs_onesweep_sort_sharded(gs_mgpu* c, const void* d_keys, const void* d
             if (!rounds_by_bin) return t.exchange(t.user, n_arrays, src_, dst_, eb_, send, sd.data(), recv, rd.data(), st_);
             const bool grouped = c->owns_comm && rccl() != nullptr;
             int e = grouped ? rccl()->GroupStart() : 0;
+            gs::MsdSegments own{};  // this rank's own bytes: taken out of the rounds and copied by one launch per array (msd_copy_segments_kernel)
             for (uint32_t j = 0; j < R && !e; ++j) {
                 if (gs_msd_exchange_round(c->h_table, W, c->rank, first, pre ? 1 : 0, j, sc.data(), sdp.data(), rc.data(), rdp.data(), nullptr) != GS_OK) { e = -1; break; }
+                if (sc[c->rank] && own.n < gs::RADIX) {
+                    own.seg[3 * own.n] = sdp[c->rank]; own.seg[3 * own.n + 1] = rdp[c->rank]; own.seg[3 * own.n + 2] = sc[c->rank];
+                    ++own.n;
+                    sc[c->rank] = 0; rc[c->rank] = 0;
+                }
                 e = t.exchange(t.user, n_arrays, src_, dst_, eb_, sc.data(), sdp.data(), rc.data(), rdp.data(), st_);
+            }
+            for (uint32_t a_ = 0; a_ < n_arrays && own.n && !e; ++a_) {
+                const uint32_t bps = 64;  // blocks per segment: 64 x 256 threads x 4 B per trip = 64 KiB of a segment of a few MiB per trip
+                hipLaunchKernelGGL(gs::msd_copy_segments_kernel, dim3(own.n * bps), dim3(256), 0, st_, static_cast<const uint32_t*>(src_[a_]),
+                                   static_cast<uint32_t*>(dst_[a_]), own, eb_[a_] / 4u, bps);
+                if (hipGetLastError() != hipSuccess) e = -1;
             }
             const int e2 = grouped ? rccl()->GroupEnd() : 0;
             if (grouped && (e || e2)) g_last_rccl_error = e ? e : e2;

@@ -131,4 +131,21 @@ __global__ __launch_bounds__(256) void msd_plan_kernel(const uint32_t* table, ui
     }
 }
 
+// The rank's OWN share of a bucket exchange that goes top byte by top byte: up to 256 (source offset, destination offset, count)
+// segments — elements of `words_per_elem` 4-byte words — copied by ONE launch (a hipMemcpyAsync per segment is a launch per top
+// byte: 32 of them at world 8, in front of the RCCL kernel on the same stream).  blockIdx.x = segment * blocks_per_seg + part.
+struct MsdSegments {
+    uint32_t n;
+    uint32_t seg[RADIX * 3];  // {source element, destination element, elements}
+};
+__global__ __launch_bounds__(256) void msd_copy_segments_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const MsdSegments segs,
+                                                                 uint32_t words_per_elem, uint32_t blocks_per_seg) {
+    const uint32_t i = blockIdx.x / blocks_per_seg, part = blockIdx.x % blocks_per_seg;
+    if (i >= segs.n) return;
+    const uint32_t* s = src + (size_t)segs.seg[3 * i] * words_per_elem;
+    uint32_t* d = dst + (size_t)segs.seg[3 * i + 1] * words_per_elem;
+    const size_t nw = (size_t)segs.seg[3 * i + 2] * words_per_elem;
+    for (size_t w = (size_t)part * 256u + threadIdx.x; w < nw; w += (size_t)blocks_per_seg * 256u) d[w] = s[w];
+}
+
 }  // namespace gs
