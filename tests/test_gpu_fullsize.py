@@ -183,6 +183,7 @@ def _exact_case(gpu, oracle, log2n, andc, vb, rank_mode=None, order=0, kt=0, pla
     (3 << 27, 0, 1, 0),         # class 2: descending
     (3 << 27, 2, 0, 4),         # class 2: float keys with u32 values, ascending
     ((1 << 28) + 12345, 1, 0, 8),  # class 2 at its lower border, ragged: (i32, u64) pairs ascending
+    ((1 << 29) + 77, 1, 1, 0),     # class 3 (1024 x 24) at its lower border: int32 keys, descending
 ])
 def test_two_level_plan_typed_and_descending_exact_default_routing(gpu, oracle, n, kt, order, vb):
     _exact_case(gpu, oracle, 28 + kt + 2 * order, 0, vb, order=order, kt=kt, n=n, two_level=True)
@@ -192,11 +193,6 @@ def test_maximum_size_2pow30_minus_1_exact_vs_oracle(gpu, oracle):
     """The two-level plan's largest class (n > 2^29: 1024 x 24 = 24 576-key buckets) at the largest n the API accepts, EXACT against
     the oracle's sort (test_maximum_size_2pow30_minus_1 holds properties only)."""
     _exact_case(gpu, oracle, 30, 0, 0, n=(1 << 30) - 1, two_level=True)
-
-
-def test_2pow30_minus_1_descending_int_keys_exact_vs_oracle(gpu, oracle):
-    """... and the same class mirrored: int32 keys, descending."""
-    _exact_case(gpu, oracle, 31, 0, 0, order=1, kt=1, n=(1 << 30) - 1, two_level=True)
 
 
 def test_2pow28_ballot_ranking_takes_the_lsd_plan_exact(gpu, oracle):

@@ -910,35 +910,3 @@ def test_wave_primitives_against_the_host(gpu):
     for l in range(64):
         rank[:, l] = (d[:, :l] == d[:, l:l + 1]).sum(axis=1)
     np.testing.assert_array_equal(r[:, 7], rank)                       # the multi-split's rank among equal digits
-
-
-@pytest.mark.parametrize("general", [False, True], ids=["default-routing", "tiled-pipeline"])
-@pytest.mark.parametrize("kt,order", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)])
-def test_every_consecutive_size_of_a_tile_typed_keys_both_orders(gpu, kt, order, general):
-    """The Unity tree's size ladder (GPUSortingUnity/Tests/TestBase.cs:267-301: EVERY size from one partition to two, for each of
-    the six key-type x order combinations) on our tile: every n in [8192, 16384] — all 8192 remainders of a partial last tile of the
-    tiled pipeline (8192-key tiles at these sizes), and on the default routing the single-tile kernel's last sizes and the two-launch
-    route's first 8192 — keys-only at odd n, (key, u32 value = key) pairs at even n, checked like the reference checks its ladder: by
-    its order- and type-aware Validate (no inversion; a payload travels with its key)."""
-    import torch
-    P = 8192
-    opts = {"small_path": 0, "mid_path": 0} if general else {}
-    sk = gpu.OneSweep(2 * P, order, kt, **opts)
-    sp = gpu.OneSweep(2 * P, order, kt, gpu.MODE_PAIRS, 4, **opts)
-    k = torch.empty(2 * P, dtype=torch.int32, device="cuda")
-    v = torch.empty(2 * P, dtype=torch.int32, device="cuda")
-    bad = []
-    for n in range(P, 2 * P + 1):
-        pairs = (n & 1) == 0
-        gpu.init_random(k, n, (n >> 3) % 5 if (n & 7) == 0 else 0, v if pairs else None, n=n)   # seed = size, as the reference's ladder; every 8th size skewed
-        (sp if pairs else sk).sort(k, v if pairs else None, n=n)
-        if gpu.validate(k, v if pairs else None, n, kt, order) != 0:
-            bad.append(n)
-        if (n & 1023) == 0:
-            sk.check()
-            sp.check()
-    sk.check()
-    sp.check()
-    assert not bad, (len(bad), bad[:8])
-    sk.close()
-    sp.close()
